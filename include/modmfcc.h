@@ -1,0 +1,152 @@
+/*
+ * modmfcc.h -- C ABI of libmodmfcc.so: MI355X (gfx950) MFCC + modulation-spectrum extractor.
+ *
+ * The reference (aaron-randreth/modulation-mfcc) is pure Python and has no FFI; the
+ * interface each entry point replaces is therefore a Python call site:
+ *
+ *   mm_mfcc_f32            <- librosa.feature.mfcc(y, sr, n_mfcc, win_length, hop_length,
+ *                             n_fft, fmin, fmax) as called at script/mfcc.py:387
+ *                             (rows A1-A6 of SURVEY.md section 8(a)), batched over clips
+ *   mm_num_frames          <- frame count implied by that call, used at script/mfcc.py:390
+ *   mm_logmel_f32          <- the melspectrogram + 10*log10 half of the same call (stage test)
+ *   mm_stft_power_f32      <- the stft + |.|^2 half of the same call (stage test / roofline)
+ *   mm_rfft_f32            <- the batched rFFT stage in isolation (np.fft.rfft rows; the
+ *                             "% HBM roofline (rFFT)" metric of BASELINE.json)
+ *   mm_modspec_f32         <- row A8: rFFT over every coefficient's time trajectory
+ *                             (build-defined; no reference site)
+ *   mm_mfcc_change_f64     <- script/mfcc.py:392-427 (drop c0, Butterworth sosfiltfilt,
+ *                             gradient, norm, output filter) -- row N1
+ *   mm_build_window/mel/dct<- scipy.signal.get_window('hann'), librosa.filters.mel,
+ *                             scipy.fftpack.dct(type=2, norm='ortho') constant tables
+ *
+ * Contract:
+ *   - plain pointers and sizes only; every data/workspace pointer is DEVICE memory owned by
+ *     the caller (e.g. torch tensor.data_ptr()); the plan owns only constant device tables;
+ *   - every compute call is asynchronous on the caller's hipStream_t (passed as void*), does
+ *     no allocation and no synchronisation (graph-capture safe);
+ *   - functions return MM_OK (0) or a negative mm_status; nothing throws, nothing exits;
+ *   - a plan is immutable after creation and bound to the device current at creation.
+ */
+#ifndef MODMFCC_H
+#define MODMFCC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_VERSION 100 /* 0.1.0 */
+
+typedef enum mm_status {
+  MM_OK = 0,
+  MM_ERR_INVALID_ARG = -1,  /* NULL pointer, non-positive size, fmax <= fmin ...              */
+  MM_ERR_UNSUPPORTED = -2,  /* n_fft not a power of two in [32, 4096], center == 0 ...        */
+  MM_ERR_HIP = -3,          /* a HIP runtime call failed (see mm_last_hip_error)              */
+  MM_ERR_WORKSPACE = -4,    /* workspace smaller than mm_workspace_bytes()                    */
+  MM_ERR_ALLOC = -5
+} mm_status;
+
+/* POD configuration; mirrors the keyword arguments of the librosa call at script/mfcc.py:387
+ * plus the build's extensions (n_mels, preemph, top_db, amin, n_mod_fft). */
+typedef struct mm_config {
+  double sr;          /* sample rate in Hz (sigSr)                                            */
+  int32_t n_fft;      /* FFT length, power of two, 32..4096                                   */
+  int32_t win_length; /* int(winLen*sigSr), 1..n_fft                                          */
+  int32_t hop_length; /* int(tStep*sigSr), >= 1                                               */
+  int32_t n_mels;     /* librosa default 128; 1..256                                          */
+  int32_t n_mfcc;     /* 1..n_mels                                                            */
+  double fmin;        /* minFreq                                                              */
+  double fmax;        /* maxFreq (may exceed Nyquist: empty filters, as the reference does)   */
+  float preemph;      /* 0 = off (reference behaviour); y[n] - a*y[n-1]                       */
+  float top_db;       /* 80; < 0 disables the per-clip clamp                                  */
+  float amin;         /* 1e-10                                                                */
+  int32_t center;     /* must be 1 (librosa center=True, pad_mode='constant')                 */
+  int32_t n_mod_fft;  /* trajectory rFFT length; 0 = next power of two >= n_frames            */
+} mm_config;
+
+typedef struct mm_plan mm_plan;
+
+/* kernels whose device time mm_timing_read() reports */
+enum {
+  MM_STAGE_LOGMEL = 0,   /* fused frame+window+rFFT+power+mel+log (+per-clip max)             */
+  MM_STAGE_DCT = 1,      /* top_db clamp + DCT-II                                             */
+  MM_STAGE_MODSPEC = 2,  /* trajectory rFFT                                                   */
+  MM_STAGE_RFFT = 3,     /* stage-isolated batched rFFT                                       */
+  MM_STAGE_POWER = 4,    /* fused frame+window+rFFT+power                                     */
+  MM_STAGE_CHANGE = 5,   /* MFCC-change tail                                                  */
+  MM_STAGE_INIT = 6,     /* clip-max reset                                                    */
+  MM_NUM_STAGES = 8
+};
+
+int mm_version(void);
+const char* mm_strerror(int status);
+const char* mm_last_hip_error(void);
+
+/* ---- host-only helpers (no GPU needed) ------------------------------------------------ */
+int mm_config_default(mm_config* cfg);                           /* reference defaults      */
+int mm_config_validate(const mm_config* cfg);
+int64_t mm_num_frames(const mm_config* cfg, int64_t n_samples);  /* 1 + n_samples / hop     */
+int32_t mm_num_bins(const mm_config* cfg);                       /* n_fft/2 + 1             */
+int32_t mm_mod_fft_len(const mm_config* cfg, int64_t n_frames);  /* resolved n_mod_fft      */
+int mm_build_window(const mm_config* cfg, float* out /*[n_fft]*/);
+int mm_build_mel(const mm_config* cfg, float* out /*[n_mels][n_fft/2+1]*/);
+int mm_build_dct(const mm_config* cfg, float* out /*[n_mfcc][n_mels]*/);
+/* Butterworth low-pass as second-order sections, scipy.signal.butter(order, wn, 'low',
+ * output='sos') layout [n_sections][6]; returns the number of sections or a negative status. */
+int mm_build_butter_sos(int order, double wn, double* sos /*[(order+1)/2][6]*/);
+
+/* ---- plan ----------------------------------------------------------------------------- */
+int mm_plan_create(const mm_config* cfg, mm_plan** out);
+int mm_plan_destroy(mm_plan* plan);
+int mm_plan_config(const mm_plan* plan, mm_config* out);
+/* 0 = generic LDS radix-2 kernels, 1 = register radix-16 kernels (n_fft 512/1024/2048) */
+int mm_plan_kernel_path(const mm_plan* plan);
+/* force the generic kernels (debug / cross-check); returns previous value */
+int mm_plan_force_generic(mm_plan* plan, int on);
+size_t mm_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_samples);
+
+/* ---- compute (device pointers, async on `stream`) ---------------------------------------
+ * d_audio : float32 [batch][audio_stride], n_samples valid per clip
+ * d_mfcc  : float32 [batch][n_mfcc][n_frames]   (coefficient-major, librosa layout)          */
+int mm_mfcc_f32(mm_plan* plan, const float* d_audio, int64_t batch, int64_t n_samples,
+                int64_t audio_stride, float* d_mfcc, void* d_workspace, size_t ws_bytes,
+                void* stream);
+
+/* d_logmel : float32 [batch][n_mels][n_frames], 10*log10(max(amin, mel)) BEFORE the clamp;
+ * d_clipmax: float32 [batch], per-clip maximum of d_logmel                                   */
+int mm_logmel_f32(mm_plan* plan, const float* d_audio, int64_t batch, int64_t n_samples,
+                  int64_t audio_stride, float* d_logmel, float* d_clipmax, void* stream);
+
+/* d_power : float32 [batch][n_frames][n_fft/2+1] (frame-major)                               */
+int mm_stft_power_f32(mm_plan* plan, const float* d_audio, int64_t batch, int64_t n_samples,
+                      int64_t audio_stride, float* d_power, void* stream);
+
+/* rows of `in_len` (<= n, zero padded) real samples -> complex64 [rows][n/2+1] interleaved.  */
+int mm_rfft_f32(mm_plan* plan, const float* d_in, int64_t rows, int64_t in_len,
+                int64_t in_stride, int32_t n, float* d_out, void* stream);
+
+/* d_mfcc [batch][n_mfcc][n_frames] -> complex64 [batch][n_mfcc][n_mod/2+1]                   */
+int mm_modspec_f32(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_t n_frames,
+                   float* d_modspec, void* stream);
+
+/* MFCC-change tail (script/mfcc.py:392-427 with diffMethod='grad', outFilter 'iir' low-pass or
+ * None): d_mfcc [batch][n_mfcc][n_frames] f32 -> d_change [batch][n_frames] f64.
+ * sos1/sos2: HOST pointers to [n_sec][6] Butterworth sections (first / output filter).       */
+int mm_mfcc_change_f64(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_t n_frames,
+                       int32_t remove_first, const double* sos1, int32_t n_sec1,
+                       const double* sos2, int32_t n_sec2, double* d_change,
+                       void* d_workspace, size_t ws_bytes, void* stream);
+size_t mm_change_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_frames);
+
+/* ---- per-kernel device timing (hipEvents on the launch stream) ------------------------- */
+int mm_timing_enable(mm_plan* plan, int on);
+/* synchronises the recorded events; ms_sum[s]/count[s] = average launch duration of stage s;
+ * resets the accumulators. Arrays of MM_NUM_STAGES. */
+int mm_timing_read(mm_plan* plan, double* ms_sum, int64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODMFCC_H */

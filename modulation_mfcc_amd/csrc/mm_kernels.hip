@@ -1,0 +1,641 @@
+// libmodmfcc device code + C ABI (include/modmfcc.h).  gfx950 (MI355X / CDNA4) only.
+//
+// Hot path = what librosa.feature.mfcc does for the call at script/mfcc.py:387:
+//   A1 centre-pad + frame + periodic Hann   A2 rFFT   A3 |.|^2   A4 Slaney mel   A5 dB + per-clip
+//   80 dB clamp   A6 DCT-II ortho           A8 rFFT over coefficient trajectories (build-defined)
+//
+// Kernels in this file (generic path: any power-of-two n_fft in [32, 4096], any hop):
+//   stft_generic_kernel<MODE>  one wave per frame; half-length complex FFT (radix-2 DIT) in LDS,
+//                              real-FFT split, |.|^2, then either the power row (MODE 0) or the
+//                              CSR mel filterbank + 10*log10 + per-clip max (MODE 1)
+//   dct_clamp_kernel           top_db clamp against the per-clip max + DCT-II, lane <-> frame
+//   rfft_generic_kernel        stage-isolated batched rFFT of zero-padded rows (also the
+//                              trajectory rFFT of the modulation spectrum)
+// The register radix-16 kernels for n_fft 512/1024/2048 live in mm_fft16.hip.inc.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mm_internal.h"
+
+#define MM_TW_N 8192  // master twiddle table: exp(-2 pi i k / 8192), k < 4096
+
+static thread_local std::string g_hip_err;
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);          \
+      return MM_ERR_HIP;                                                      \
+    }                                                                         \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of ONE wave execute in order; this only stops the compiler from moving
+  // accesses across the point where lanes exchange data through the wave-private buffer.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// order-preserving float -> int key for atomicMax
+__device__ __forceinline__ int float_key(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float key_float(int k) {
+  return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// In-place radix-2 DIT over a wave-private LDS buffer; input already bit-reversed.
+__device__ __forceinline__ void wave_cfft_lds(float2* z, int log2nc, const float2* __restrict__ tw,
+                                              int lane) {
+  const int nc = 1 << log2nc;
+  for (int s = 1; s <= log2nc; ++s) {
+    const int half = 1 << (s - 1);
+    const int tw_stride = MM_TW_N >> s;
+    for (int j = lane; j < (nc >> 1); j += 64) {
+      const int pos = j & (half - 1);
+      const int i0 = ((j >> (s - 1)) << s) + pos;
+      const int i1 = i0 + half;
+      const float2 w = tw[pos * tw_stride];
+      const float2 a = z[i0];
+      const float2 t = cmul(w, z[i1]);
+      z[i0] = make_float2(a.x + t.x, a.y + t.y);
+      z[i1] = make_float2(a.x - t.x, a.y - t.y);
+    }
+    wave_lds_sync();
+  }
+}
+
+// Split the half-length complex FFT Z (nc points, in LDS) of a packed real row into the real
+// FFT bins k and nc-k.  Returns X[k] in xa and X[nc-k] in xb.
+__device__ __forceinline__ void real_split(const float2* z, int k, int nc, const float2* __restrict__ tw,
+                                           int tw_stride, float2& xa, float2& xb) {
+  const float2 a = z[k];
+  const float2 b = z[(nc - k) & (nc - 1)];
+  const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+  const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+  const float2 O = make_float2(D.y, -D.x);  // -i * D
+  const float2 t = cmul(tw[k * tw_stride], O);
+  xa = make_float2(E.x + t.x, E.y + t.y);
+  xb = make_float2(E.x - t.x, -(E.y - t.y));
+}
+
+struct StftParams {
+  const float* audio;
+  int64_t batch, n_samples, stride, n_frames;
+  int n_fft, log2nc, hop, n_bins, n_mels;
+  float preemph, amin, db_offset;
+  const float* window;
+  const float2* tw;
+  const int* mel_start;
+  const int* mel_len;
+  const int* mel_off;
+  const float* mel_w;
+  float* out_power;   // MODE 0: [B][T][n_bins]
+  float* out_logmel;  // MODE 1: [B][n_mels][T]
+  int* clip_key;      // MODE 1: [B]
+  int frames_per_wave;
+};
+
+__device__ __forceinline__ float load_sample(const float* __restrict__ a, int64_t i, int64_t n,
+                                             float pre) {
+  if (i < 0 || i >= n) return 0.0f;
+  float v = a[i];
+  if (pre != 0.0f && i > 0) v -= pre * a[i - 1];
+  return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void stft_generic_kernel(StftParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nc = 1 << p.log2nc;
+  const size_t wave_bytes = ((size_t)nc * 8 + (size_t)(nc + 1) * 4 + 15) & ~(size_t)15;
+  float2* z = reinterpret_cast<float2*>(smem + wave * wave_bytes);
+  float* P = reinterpret_cast<float*>(smem + wave * wave_bytes + (size_t)nc * 8);
+
+  const int fpb = 4 * p.frames_per_wave;
+  const int64_t tiles = (p.n_frames + fpb - 1) / fpb;
+  const int64_t b = blockIdx.x / tiles;
+  const int64_t t0 = (blockIdx.x % tiles) * fpb + (int64_t)wave * p.frames_per_wave;
+  const float* a = p.audio + b * p.stride;
+  const int tw_stride = MM_TW_N / p.n_fft;
+  float vmax = -INFINITY;
+
+  for (int f = 0; f < p.frames_per_wave; ++f) {
+    const int64_t t = t0 + f;
+    if (t >= p.n_frames) break;  // wave-uniform
+    const int64_t base = t * p.hop - (p.n_fft >> 1);
+    for (int n = lane; n < nc; n += 64) {
+      const float x0 = load_sample(a, base + 2 * n, p.n_samples, p.preemph) * p.window[2 * n];
+      const float x1 = load_sample(a, base + 2 * n + 1, p.n_samples, p.preemph) * p.window[2 * n + 1];
+      z[__brev((unsigned)n) >> (32 - p.log2nc)] = make_float2(x0, x1);
+    }
+    wave_lds_sync();
+    wave_cfft_lds(z, p.log2nc, p.tw, lane);
+    for (int k = lane; k <= (nc >> 1); k += 64) {
+      float2 xa, xb;
+      real_split(z, k, nc, p.tw, tw_stride, xa, xb);
+      P[k] = xa.x * xa.x + xa.y * xa.y;
+      P[nc - k] = xb.x * xb.x + xb.y * xb.y;
+    }
+    wave_lds_sync();
+    if (MODE == 0) {
+      float* o = p.out_power + (b * p.n_frames + t) * p.n_bins;
+      for (int k = lane; k < p.n_bins; k += 64) o[k] = P[k];
+    } else {
+      for (int m = lane; m < p.n_mels; m += 64) {
+        const float* w = p.mel_w + p.mel_off[m];
+        const float* pp = P + p.mel_start[m];
+        const int len = p.mel_len[m];
+        float acc = 0.0f;
+        for (int j = 0; j < len; ++j) acc = fmaf(w[j], pp[j], acc);
+        const float db = 10.0f * log10f(fmaxf(p.amin, acc)) - p.db_offset;
+        p.out_logmel[(b * p.n_mels + m) * p.n_frames + t] = db;
+        vmax = fmaxf(vmax, db);
+      }
+    }
+    wave_lds_sync();
+  }
+  if (MODE == 1) {
+    vmax = wave_max(vmax);
+    if (lane == 0 && vmax > -INFINITY) atomicMax(p.clip_key + b, float_key(vmax));
+  }
+}
+
+// Clamp against the per-clip max and apply the DCT-II matrix.  lane <-> frame so that both the
+// logmel reads [B][n_mels][T] and the MFCC writes [B][n_mfcc][T] are coalesced; the DCT row
+// index is wave-uniform, so the coefficients come through the scalar cache.
+#define MM_DCT_KB 16
+__global__ __launch_bounds__(256) void dct_clamp_kernel(const float* __restrict__ logmel,
+                                                         const int* __restrict__ clip_key,
+                                                         const float* __restrict__ dct_t /*[n_mels][KP]*/,
+                                                         float* __restrict__ out, int64_t n_frames,
+                                                         int n_mels, int n_mfcc, int kp, float top_db) {
+  const int64_t bpc = (n_frames + 255) / 256;
+  const int64_t b = blockIdx.x / bpc;
+  const int64_t t = (blockIdx.x % bpc) * 256 + threadIdx.x;
+  if (t >= n_frames) return;
+  const float thr = top_db >= 0.0f ? key_float(clip_key[b]) - top_db : -INFINITY;
+  const float* lm = logmel + b * n_mels * n_frames + t;
+  float* o = out + b * n_mfcc * n_frames + t;
+  for (int k0 = 0; k0 < n_mfcc; k0 += MM_DCT_KB) {
+    float acc[MM_DCT_KB];
+#pragma unroll
+    for (int kk = 0; kk < MM_DCT_KB; ++kk) acc[kk] = 0.0f;
+    for (int m = 0; m < n_mels; ++m) {
+      const float x = fmaxf(lm[(int64_t)m * n_frames], thr);
+      const float* d = dct_t + (size_t)m * kp + k0;
+#pragma unroll
+      for (int kk = 0; kk < MM_DCT_KB; ++kk) acc[kk] = fmaf(d[kk], x, acc[kk]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < MM_DCT_KB; ++kk)
+      if (k0 + kk < n_mfcc) o[(int64_t)(k0 + kk) * n_frames] = acc[kk];
+  }
+}
+
+__global__ void decode_keys_kernel(int* inout, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) reinterpret_cast<float*>(inout)[i] = key_float(inout[i]);
+}
+
+struct RfftParams {
+  const float* in;
+  int64_t rows, in_len, in_stride;
+  int n, log2nc, rows_per_wave;
+  const float2* tw;
+  float* out;  // complex64 [rows][n/2+1]
+};
+
+__global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nc = 1 << p.log2nc;
+  float2* z = reinterpret_cast<float2*>(smem) + (size_t)wave * nc;
+  const int tw_stride = MM_TW_N / p.n;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * p.rows_per_wave;
+  for (int f = 0; f < p.rows_per_wave; ++f) {
+    const int64_t r = r0 + f;
+    if (r >= p.rows) break;
+    const float* a = p.in + r * p.in_stride;
+    for (int n = lane; n < nc; n += 64) {
+      const float x0 = (2 * n < p.in_len) ? a[2 * n] : 0.0f;
+      const float x1 = (2 * n + 1 < p.in_len) ? a[2 * n + 1] : 0.0f;
+      z[__brev((unsigned)n) >> (32 - p.log2nc)] = make_float2(x0, x1);
+    }
+    wave_lds_sync();
+    wave_cfft_lds(z, p.log2nc, p.tw, lane);
+    float2* o = reinterpret_cast<float2*>(p.out) + r * (nc + 1);
+    for (int k = lane; k <= (nc >> 1); k += 64) {
+      float2 xa, xb;
+      real_split(z, k, nc, p.tw, tw_stride, xa, xb);
+      o[k] = xa;
+      o[nc - k] = xb;
+    }
+    wave_lds_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+#define MM_MAX_TIMED 16384
+
+struct mm_plan {
+  mm_config cfg;
+  int device;
+  int n_bins, log2nc, kp;
+  float db_offset;
+  int path;           // 0 generic, 1 radix-16 register kernels
+  int force_generic;
+  float* d_window;
+  float2* d_tw;
+  int *d_mel_start, *d_mel_len, *d_mel_off;
+  float* d_mel_w;
+  float* d_dct_t;
+  // timing
+  int timing_on;
+  std::vector<hipEvent_t> ev_pool;  // pairs
+  std::vector<int> ev_stage;
+  int ev_used;
+  double t_sum[MM_NUM_STAGES];
+  int64_t t_cnt[MM_NUM_STAGES];
+};
+
+namespace {
+
+struct StageTimer {
+  mm_plan* p;
+  hipStream_t s;
+  int idx;
+  StageTimer(mm_plan* plan, int stage, hipStream_t stream) : p(plan), s(stream), idx(-1) {
+    if (!p->timing_on || p->ev_used >= MM_MAX_TIMED) return;
+    if ((size_t)(2 * p->ev_used + 1) >= p->ev_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      p->ev_pool.push_back(a);
+      p->ev_pool.push_back(b);
+    }
+    idx = p->ev_used++;
+    p->ev_stage.resize(p->ev_used);
+    p->ev_stage[idx] = stage;
+    (void)hipEventRecord(p->ev_pool[2 * idx], s);
+  }
+  ~StageTimer() {
+    if (idx >= 0) (void)hipEventRecord(p->ev_pool[2 * idx + 1], s);
+  }
+};
+
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+template <class T>
+int upload(T** dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMalloc((void**)dst, bytes));
+  HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return MM_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int mm_version(void) { return MM_VERSION; }
+
+const char* mm_strerror(int s) {
+  switch (s) {
+    case MM_OK: return "ok";
+    case MM_ERR_INVALID_ARG: return "invalid argument";
+    case MM_ERR_UNSUPPORTED: return "unsupported configuration";
+    case MM_ERR_HIP: return "HIP runtime error";
+    case MM_ERR_WORKSPACE: return "workspace too small";
+    case MM_ERR_ALLOC: return "allocation failed";
+    default: return "unknown status";
+  }
+}
+
+const char* mm_last_hip_error(void) { return g_hip_err.c_str(); }
+
+int mm_config_default(mm_config* c) {
+  if (!c) return MM_ERR_INVALID_ARG;
+  // defaults of get_MFCCS_change as the UI calls it (script/main.py:732-748) at 10 kHz
+  c->sr = 10000.0;
+  c->n_fft = 512;
+  c->win_length = 250;
+  c->hop_length = 50;
+  c->n_mels = 128;
+  c->n_mfcc = 13;
+  c->fmin = 100.0;
+  c->fmax = 10000.0;
+  c->preemph = 0.0f;
+  c->top_db = 80.0f;
+  c->amin = 1e-10f;
+  c->center = 1;
+  c->n_mod_fft = 0;
+  return MM_OK;
+}
+
+int mm_config_validate(const mm_config* c) { return mm::validate(c); }
+
+int64_t mm_num_frames(const mm_config* c, int64_t n_samples) {
+  if (!c || c->hop_length < 1 || n_samples < 0) return MM_ERR_INVALID_ARG;
+  return 1 + n_samples / c->hop_length;
+}
+
+int32_t mm_num_bins(const mm_config* c) { return c ? c->n_fft / 2 + 1 : MM_ERR_INVALID_ARG; }
+
+int32_t mm_mod_fft_len(const mm_config* c, int64_t n_frames) {
+  if (!c || n_frames < 1) return MM_ERR_INVALID_ARG;
+  if (c->n_mod_fft) return c->n_mod_fft >= n_frames ? c->n_mod_fft : MM_ERR_INVALID_ARG;
+  int64_t n = 32;
+  while (n < n_frames) n *= 2;
+  return n <= 4096 ? (int32_t)n : MM_ERR_UNSUPPORTED;
+}
+
+int mm_build_window(const mm_config* c, float* out) {
+  int s = mm::validate(c);
+  if (s || !out) return s ? s : MM_ERR_INVALID_ARG;
+  mm::build_window(*c, out);
+  return MM_OK;
+}
+int mm_build_mel(const mm_config* c, float* out) {
+  int s = mm::validate(c);
+  if (s || !out) return s ? s : MM_ERR_INVALID_ARG;
+  mm::build_mel(*c, out);
+  return MM_OK;
+}
+int mm_build_dct(const mm_config* c, float* out) {
+  int s = mm::validate(c);
+  if (s || !out) return s ? s : MM_ERR_INVALID_ARG;
+  mm::build_dct(*c, out);
+  return MM_OK;
+}
+int mm_build_butter_sos(int order, double wn, double* sos) { return mm::build_butter_sos(order, wn, sos); }
+
+int mm_plan_create(const mm_config* cfg, mm_plan** out) {
+  if (!out) return MM_ERR_INVALID_ARG;
+  *out = nullptr;
+  int s = mm::validate(cfg);
+  if (s) return s;
+  mm_plan* p = new (std::nothrow) mm_plan();
+  if (!p) return MM_ERR_ALLOC;
+  p->cfg = *cfg;
+  p->n_bins = cfg->n_fft / 2 + 1;
+  p->log2nc = ilog2(cfg->n_fft) - 1;
+  p->kp = (cfg->n_mfcc + MM_DCT_KB - 1) / MM_DCT_KB * MM_DCT_KB;
+  p->db_offset = 10.0f * log10f(fmaxf(cfg->amin, 1.0f));
+  p->path = 0;
+  p->force_generic = 0;
+  p->timing_on = 0;
+  p->ev_used = 0;
+  std::memset(p->t_sum, 0, sizeof(p->t_sum));
+  std::memset(p->t_cnt, 0, sizeof(p->t_cnt));
+  p->d_window = nullptr; p->d_tw = nullptr; p->d_mel_start = p->d_mel_len = p->d_mel_off = nullptr;
+  p->d_mel_w = nullptr; p->d_dct_t = nullptr;
+  if (hipGetDevice(&p->device) != hipSuccess) {
+    g_hip_err = "hipGetDevice failed (no GPU?)";
+    delete p;
+    return MM_ERR_HIP;
+  }
+  std::vector<float> win(cfg->n_fft), mel((size_t)cfg->n_mels * p->n_bins),
+      dct((size_t)cfg->n_mfcc * cfg->n_mels), dct_t((size_t)cfg->n_mels * p->kp, 0.0f),
+      tw(MM_TW_N);
+  mm::build_window(*cfg, win.data());
+  mm::build_mel(*cfg, mel.data());
+  mm::build_dct(*cfg, dct.data());
+  mm::build_twiddles(MM_TW_N, tw.data());
+  for (int k = 0; k < cfg->n_mfcc; ++k)
+    for (int m = 0; m < cfg->n_mels; ++m) dct_t[(size_t)m * p->kp + k] = dct[(size_t)k * cfg->n_mels + m];
+  mm::MelCsr csr;
+  mm::build_mel_csr(*cfg, mel.data(), &csr);
+  int rc = MM_OK;
+  if ((rc = upload(&p->d_window, win.data(), win.size() * 4)) ||
+      (rc = upload(&p->d_tw, tw.data(), tw.size() * 4)) ||
+      (rc = upload(&p->d_mel_start, csr.start.data(), csr.start.size() * 4)) ||
+      (rc = upload(&p->d_mel_len, csr.len.data(), csr.len.size() * 4)) ||
+      (rc = upload(&p->d_mel_off, csr.off.data(), csr.off.size() * 4)) ||
+      (rc = upload(&p->d_mel_w, csr.w.data(), csr.w.size() * 4)) ||
+      (rc = upload(&p->d_dct_t, dct_t.data(), dct_t.size() * 4))) {
+    mm_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return MM_OK;
+}
+
+int mm_plan_destroy(mm_plan* p) {
+  if (!p) return MM_OK;
+  (void)hipFree(p->d_window); (void)hipFree(p->d_tw); (void)hipFree(p->d_mel_start);
+  (void)hipFree(p->d_mel_len); (void)hipFree(p->d_mel_off); (void)hipFree(p->d_mel_w);
+  (void)hipFree(p->d_dct_t);
+  for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+  delete p;
+  return MM_OK;
+}
+
+int mm_plan_config(const mm_plan* p, mm_config* out) {
+  if (!p || !out) return MM_ERR_INVALID_ARG;
+  *out = p->cfg;
+  return MM_OK;
+}
+
+int mm_plan_kernel_path(const mm_plan* p) { return p ? (p->force_generic ? 0 : p->path) : MM_ERR_INVALID_ARG; }
+
+int mm_plan_force_generic(mm_plan* p, int on) {
+  if (!p) return MM_ERR_INVALID_ARG;
+  int prev = p->force_generic;
+  p->force_generic = on ? 1 : 0;
+  return prev;
+}
+
+size_t mm_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_samples) {
+  if (!p || batch < 1 || n_samples < 0) return 0;
+  const int64_t T = mm_num_frames(&p->cfg, n_samples);
+  return align_up((size_t)batch * p->cfg.n_mels * T * 4, 256) + align_up((size_t)batch * 4, 256);
+}
+
+static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch, int64_t n_samples,
+                       int64_t stride, float* out_power, float* out_logmel, int* clip_key,
+                       hipStream_t st) {
+  StftParams q;
+  q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
+  q.n_frames = mm_num_frames(&p->cfg, n_samples);
+  q.n_fft = p->cfg.n_fft; q.log2nc = p->log2nc; q.hop = p->cfg.hop_length; q.n_bins = p->n_bins;
+  q.n_mels = p->cfg.n_mels; q.preemph = p->cfg.preemph; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
+  q.window = p->d_window; q.tw = p->d_tw; q.mel_start = p->d_mel_start; q.mel_len = p->d_mel_len;
+  q.mel_off = p->d_mel_off; q.mel_w = p->d_mel_w; q.out_power = out_power; q.out_logmel = out_logmel;
+  q.clip_key = clip_key; q.frames_per_wave = 4;
+  const int nc = 1 << p->log2nc;
+  const size_t wave_bytes = ((size_t)nc * 8 + (size_t)(nc + 1) * 4 + 15) & ~(size_t)15;
+  const int fpb = 4 * q.frames_per_wave;
+  const int64_t tiles = (q.n_frames + fpb - 1) / fpb;
+  const int64_t grid = batch * tiles;
+  if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  if (mode == 0)
+    hipLaunchKernelGGL(stft_generic_kernel<0>, dim3((unsigned)grid), dim3(256), 4 * wave_bytes, st, q);
+  else
+    hipLaunchKernelGGL(stft_generic_kernel<1>, dim3((unsigned)grid), dim3(256), 4 * wave_bytes, st, q);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
+static int check_audio_args(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_samples,
+                            int64_t stride) {
+  if (!p || !d_audio || batch < 1 || n_samples < 1 || stride < n_samples) return MM_ERR_INVALID_ARG;
+  if (n_samples > ((int64_t)1 << 31) - 8192) return MM_ERR_INVALID_ARG;
+  return MM_OK;
+}
+
+int mm_stft_power_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_samples,
+                      int64_t stride, float* d_power, void* stream) {
+  int rc = check_audio_args(p, d_audio, batch, n_samples, stride);
+  if (rc || !d_power) return rc ? rc : MM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  StageTimer tm(p, MM_STAGE_POWER, st);
+  return launch_stft(p, 0, d_audio, batch, n_samples, stride, d_power, nullptr, nullptr, st);
+}
+
+int mm_logmel_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_samples, int64_t stride,
+                  float* d_logmel, float* d_clipmax, void* stream) {
+  int rc = check_audio_args(p, d_audio, batch, n_samples, stride);
+  if (rc || !d_logmel || !d_clipmax) return rc ? rc : MM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(d_clipmax, 0x80, (size_t)batch * 4, st));
+  {
+    StageTimer tm(p, MM_STAGE_LOGMEL, st);
+    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, nullptr, d_logmel, (int*)d_clipmax, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(decode_keys_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st,
+                     (int*)d_clipmax, batch);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
+int mm_mfcc_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_samples, int64_t stride,
+                float* d_mfcc, void* d_ws, size_t ws_bytes, void* stream) {
+  int rc = check_audio_args(p, d_audio, batch, n_samples, stride);
+  if (rc || !d_mfcc || !d_ws) return rc ? rc : MM_ERR_INVALID_ARG;
+  if (ws_bytes < mm_workspace_bytes(p, batch, n_samples)) return MM_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t T = mm_num_frames(&p->cfg, n_samples);
+  float* logmel = (float*)d_ws;
+  int* keys = (int*)((char*)d_ws + align_up((size_t)batch * p->cfg.n_mels * T * 4, 256));
+  {
+    StageTimer tm(p, MM_STAGE_INIT, st);
+    HIP_TRY(hipMemsetAsync(keys, 0x80, (size_t)batch * 4, st));
+  }
+  {
+    StageTimer tm(p, MM_STAGE_LOGMEL, st);
+    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, nullptr, logmel, keys, st);
+    if (rc) return rc;
+  }
+  {
+    StageTimer tm(p, MM_STAGE_DCT, st);
+    const int64_t bpc = (T + 255) / 256;
+    if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(dct_clamp_kernel, dim3((unsigned)(batch * bpc)), dim3(256), 0, st, logmel, keys,
+                       p->d_dct_t, d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
+    HIP_TRY(hipGetLastError());
+  }
+  return MM_OK;
+}
+
+static int launch_rfft(mm_plan* p, const float* d_in, int64_t rows, int64_t in_len, int64_t in_stride,
+                       int n, float* d_out, hipStream_t st) {
+  RfftParams q;
+  q.in = d_in; q.rows = rows; q.in_len = in_len; q.in_stride = in_stride; q.n = n;
+  q.log2nc = ilog2(n) - 1; q.rows_per_wave = 4; q.tw = p->d_tw; q.out = d_out;
+  const int nc = n / 2;
+  const int64_t grid = (rows + 4 * q.rows_per_wave - 1) / (4 * q.rows_per_wave);
+  if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(rfft_generic_kernel, dim3((unsigned)grid), dim3(256), (size_t)4 * nc * 8, st, q);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
+int mm_rfft_f32(mm_plan* p, const float* d_in, int64_t rows, int64_t in_len, int64_t in_stride,
+                int32_t n, float* d_out, void* stream) {
+  if (!p || !d_in || !d_out || rows < 1 || in_len < 1 || in_stride < in_len) return MM_ERR_INVALID_ARG;
+  if (n < 32 || n > 4096 || (n & (n - 1))) return MM_ERR_UNSUPPORTED;
+  if (in_len > n) return MM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  StageTimer tm(p, MM_STAGE_RFFT, st);
+  return launch_rfft(p, d_in, rows, in_len, in_stride, n, d_out, st);
+}
+
+int mm_modspec_f32(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_frames, float* d_out,
+                   void* stream) {
+  if (!p || !d_mfcc || !d_out || batch < 1 || n_frames < 1) return MM_ERR_INVALID_ARG;
+  const int n = mm_mod_fft_len(&p->cfg, n_frames);
+  if (n < 0) return n;
+  hipStream_t st = (hipStream_t)stream;
+  StageTimer tm(p, MM_STAGE_MODSPEC, st);
+  return launch_rfft(p, d_mfcc, batch * p->cfg.n_mfcc, n_frames, n_frames, n, d_out, st);
+}
+
+size_t mm_change_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_frames) {
+  (void)p; (void)batch; (void)n_frames;
+  return 0;
+}
+
+int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_frames,
+                       int32_t remove_first, const double* sos1, int32_t n_sec1, const double* sos2,
+                       int32_t n_sec2, double* d_change, void* d_ws, size_t ws_bytes, void* stream) {
+  (void)p; (void)d_mfcc; (void)batch; (void)n_frames; (void)remove_first; (void)sos1; (void)n_sec1;
+  (void)sos2; (void)n_sec2; (void)d_change; (void)d_ws; (void)ws_bytes; (void)stream;
+  return MM_ERR_UNSUPPORTED;  // row N1: not built yet
+}
+
+int mm_timing_enable(mm_plan* p, int on) {
+  if (!p) return MM_ERR_INVALID_ARG;
+  p->timing_on = on ? 1 : 0;
+  return MM_OK;
+}
+
+int mm_timing_read(mm_plan* p, double* ms_sum, int64_t* count) {
+  if (!p || !ms_sum || !count) return MM_ERR_INVALID_ARG;
+  for (int i = 0; i < p->ev_used; ++i) {
+    HIP_TRY(hipEventSynchronize(p->ev_pool[2 * i + 1]));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[2 * i], p->ev_pool[2 * i + 1]));
+    p->t_sum[p->ev_stage[i]] += ms;
+    p->t_cnt[p->ev_stage[i]] += 1;
+  }
+  p->ev_used = 0;
+  for (int s = 0; s < MM_NUM_STAGES; ++s) {
+    ms_sum[s] = p->t_sum[s];
+    count[s] = p->t_cnt[s];
+    p->t_sum[s] = 0.0;
+    p->t_cnt[s] = 0;
+  }
+  return MM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Fixture -> (oracle cfg kwargs, regenerated input clip, dict of expected arrays)."""
+    import mfcc_oracle as O
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    kw = {k: v for k, v in zip(z["cfg_keys"].tolist(), z["cfg_vals"].tolist())}
+    for k in ("sr", "n_fft", "win_length", "hop_length", "n_mels", "n_mfcc"):
+        kw[k] = int(kw[k])
+    seed, n = (int(v) for v in z["recipe"])
+    y = O.synth_clip(seed, n, kw["sr"], str(z["kind"]))
+    assert int(np.abs(y).sum() * 1e6) == int(z["audio_crc"][0]), "input recipe drifted"
+    return kw, y, {k: z[k] for k in z.files}
+
+
+GOLDEN_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz")) \
+    if os.path.isdir(GOLDEN) else []
+
+
+def mfcc_close(a, b, what=""):
+    """North-star tolerance: 1e-4 relative to the clip's max |MFCC| AND elementwise
+    |a-b| <= 1e-4*|b| + 1e-3 (MFCCs are dB-derived and cross zero)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    err = np.abs(a - b)
+    assert err.max() <= 1e-4 * scale, f"{what}: max err {err.max():.3e} vs 1e-4*{scale:.3e}"
+    bad = err > 1e-4 * np.abs(b) + 1e-3
+    assert not bad.any(), f"{what}: {bad.sum()} elements beyond 1e-4*|b|+1e-3 (worst {err.max():.3e})"
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but torch.cuda.is_available() is False")
+    return torch.device("cuda", 0)

@@ -1,0 +1,121 @@
+"""CPU: libmodmfcc.so loads, exports every symbol include/modmfcc.h declares, and its host-only
+table builders reproduce the oracle's tables.  No GPU compute is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.fftpack
+import scipy.signal
+
+import mfcc_oracle as O
+from conftest import ROOT
+from modulation_mfcc_amd import _lib
+from modulation_mfcc_amd.plan import MfccConfig, butter_sos
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "modmfcc.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/modmfcc.h but not exported"
+    assert set(syms) == set(_lib.PROTOTYPES), set(syms) ^ set(_lib.PROTOTYPES)
+    assert lib.mm_version() == 100
+    assert lib.mm_strerror(-2) == b"unsupported configuration"
+
+
+def test_config_struct_layout_and_defaults():
+    lib = _lib.load()
+    c = _lib.mm_config()
+    assert lib.mm_config_default(C.byref(c)) == 0
+    # script/main.py:732-748 at 10 kHz: 25 ms / 5 ms, 13 MFCC, n_fft 512, 100..10000 Hz
+    assert (c.sr, c.n_fft, c.win_length, c.hop_length, c.n_mels, c.n_mfcc) == (10000.0, 512, 250, 50, 128, 13)
+    assert (c.fmin, c.fmax, c.center, c.n_mod_fft) == (100.0, 10000.0, 1, 0)
+    assert c.top_db == 80.0 and abs(c.amin - 1e-10) < 1e-17
+    assert lib.mm_config_validate(C.byref(c)) == 0
+    assert lib.mm_num_frames(C.byref(c), 10000) == 201
+    assert lib.mm_num_bins(C.byref(c)) == 257
+    assert lib.mm_mod_fft_len(C.byref(c), 1001) == 1024
+
+
+@pytest.mark.parametrize("bad,exc", [
+    (dict(n_fft=500), NotImplementedError), (dict(n_fft=8192), NotImplementedError),
+    (dict(win_length=600), ValueError), (dict(hop_length=0), ValueError),
+    (dict(n_mfcc=200), ValueError), (dict(fmax=50.0), ValueError), (dict(center=False), NotImplementedError),
+    (dict(amin=0.0), ValueError), (dict(n_mod_fft=1000), NotImplementedError),
+])
+def test_validate_rejects(bad, exc):
+    with pytest.raises(exc):
+        MfccConfig(**bad).validate()
+
+
+def test_reference_call_truncation():
+    # script/mfcc.py:382-384: int(0.025*22050)=551, int(0.01*22050)=220
+    c = MfccConfig.from_reference_call(22050, tStep=0.01, winLen=0.025, n_fft=1024)
+    assert (c.win_length, c.hop_length, c.n_mels) == (551, 220, 128)
+    c = MfccConfig.from_reference_call(10000, tStep=0.005, winLen=0.025)
+    assert (c.win_length, c.hop_length, c.fmax) == (250, 50, 10000.0)
+    assert c.num_frames(10000) == 201
+
+
+CFGS = [
+    dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0),
+    dict(sr=10000, n_fft=512, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0),
+    dict(sr=48000, n_fft=2048, win_length=1200, hop_length=480, n_mels=80, n_mfcc=40, fmin=100.0, fmax=10000.0),
+    dict(sr=22050, n_fft=1024, win_length=551, hop_length=220, n_mels=64, n_mfcc=20, fmin=0.0, fmax=11025.0),
+    dict(sr=8000, n_fft=256, win_length=255, hop_length=3, n_mels=23, n_mfcc=23, fmin=20.0, fmax=3900.0),
+]
+
+
+@pytest.mark.parametrize("kw", CFGS)
+def test_host_tables_match_oracle(kw):
+    c = MfccConfig(**kw)
+    W = O.mel_filterbank(kw["sr"], kw["n_fft"], kw["n_mels"], kw["fmin"], kw["fmax"])
+    got = c.mel_filterbank()
+    assert got.shape == W.shape
+    np.testing.assert_allclose(got, W, rtol=3e-7, atol=1e-12)
+    assert ((got == 0) == (W == 0)).all()
+    w = O.hann_window_padded(kw["win_length"], kw["n_fft"]).astype(np.float32)
+    np.testing.assert_allclose(c.window(), w, rtol=0, atol=6e-8)
+    D = scipy.fftpack.dct(np.eye(kw["n_mels"]), axis=0, type=2, norm="ortho")[:kw["n_mfcc"]]
+    np.testing.assert_allclose(c.dct_matrix(), D, rtol=0, atol=3e-8)
+
+
+def test_butter_sos_matches_scipy():
+    for order in range(1, 11):
+        for wn in (0.003, 0.048, 0.12, 0.3, 0.5, 0.66, 0.9):
+            np.testing.assert_allclose(butter_sos(order, wn), scipy.signal.butter(order, wn, output="sos"),
+                                       rtol=1e-12, atol=1e-14)
+    with pytest.raises(ValueError):
+        butter_sos(6, 1.5)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from modulation_mfcc_amd import get_MFCCS_change, MfccPlan
+    with pytest.raises(RuntimeError):
+        MfccPlan(MfccConfig())
+    with pytest.raises(RuntimeError):
+        get_MFCCS_change(np.zeros(1000, dtype=np.float32), 10000)
+
+
+def test_package_does_not_import_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; import modulation_mfcc_amd, modulation_mfcc_amd.mfcc, modulation_mfcc_amd.calc;"
+            "assert not any('oracle' in m for m in sys.modules), [m for m in sys.modules if 'oracle' in m]")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "modulation_mfcc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".inc")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().lower().replace("# oracle", ""), f

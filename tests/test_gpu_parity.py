@@ -1,0 +1,183 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden vectors.
+
+Tolerance (north star / SURVEY 8(c)): MFCC within 1e-4 relative -- ``mfcc_close`` checks
+max|a-b| <= 1e-4 * max|b| per clip AND |a-b| <= 1e-4*|b| + 1e-3 elementwise.
+"""
+import numpy as np
+import pytest
+
+import mfcc_oracle as O
+from conftest import GOLDEN_NAMES, load_golden, mfcc_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(kw, **extra):
+    from modulation_mfcc_amd import MfccConfig, get_plan
+    return get_plan(MfccConfig(**{**kw, **extra}))
+
+
+def _dev(x, gpu):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).to(gpu)
+
+
+def test_native_library_is_loaded(gpu):
+    from modulation_mfcc_amd import _lib
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libmodmfcc.so" in maps
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_mfcc_matches_golden(name, generic, gpu):
+    kw, y, exp = load_golden(name)
+    plan = _plan(kw)
+    plan.force_generic(generic)
+    try:
+        got = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
+    finally:
+        plan.force_generic(False)
+    mfcc_close(got, exp["mfcc"], f"{name} generic={generic}")
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_stage_outputs_match_oracle(generic, gpu):
+    kw, y, exp = load_golden("c1_am")
+    plan = _plan(kw)
+    plan.force_generic(generic)
+    try:
+        d = _dev(y, gpu)[None, :]
+        P = plan.stft_power(d)[0].cpu().numpy()
+        lm, mx = plan.logmel(d)
+        lm, mx = lm[0].cpu().numpy(), float(mx[0])
+    finally:
+        plan.force_generic(False)
+    Pw = O.stft_power(y, kw["n_fft"], kw["hop_length"], kw["win_length"])
+    assert P.shape == Pw.shape
+    np.testing.assert_allclose(P, Pw, rtol=2e-4, atol=1e-5 * Pw.max())
+    np.testing.assert_allclose(P[:8], exp["power_first8"], rtol=2e-4, atol=1e-5 * Pw.max())
+    want = exp["logmel_unclamped"].T           # [n_mels, T]
+    np.testing.assert_allclose(lm, want, rtol=0, atol=2e-3)
+    assert mx == pytest.approx(float(want.max()), abs=2e-3)
+
+
+def test_clamp_path_is_exercised(gpu):
+    kw, y, exp = load_golden("c1_quiet_tail")
+    lm = exp["logmel_unclamped"]
+    assert lm.min() < lm.max() - 80.0           # the fixture really clamps
+    plan = _plan(kw)
+    got = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
+    mfcc_close(got, exp["mfcc"], "quiet_tail")
+    noclamp = _plan(kw, top_db=-1.0).mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
+    assert np.abs(noclamp - exp["mfcc"]).max() > 1.0
+
+
+def test_batch_rows_are_independent_and_strided(gpu):
+    import torch
+    kw, _, _ = load_golden("c1_am")
+    cfg = O.OracleConfig(**kw)
+    n = 4000
+    clips = np.stack([O.synth_clip(100 + i, n, kw["sr"], k) for i, k in
+                      enumerate(["am", "noise", "silence", "quiet_tail", "chirp", "impulse", "am"])])
+    plan = _plan(kw)
+    big = torch.zeros((clips.shape[0], n + 37), dtype=torch.float32, device=gpu)
+    big[:, :n] = _dev(clips, gpu)
+    got = plan.mfcc(big[:, :n]).cpu().numpy()          # non-contiguous rows (stride n+37)
+    for i in range(clips.shape[0]):
+        mfcc_close(got[i], O.mfcc(clips[i], cfg), f"clip {i}")
+    again = plan.mfcc(_dev(clips[3:4], gpu)).cpu().numpy()
+    np.testing.assert_array_equal(again[0], got[3])   # bit-identical regardless of batch position
+
+
+@pytest.mark.parametrize("n,L", [(512, 512), (1024, 1001), (2048, 2048), (64, 40), (4096, 4096), (256, 1)])
+def test_rfft_rows(n, L, gpu):
+    rng = np.random.default_rng(n + L)
+    x = rng.standard_normal((37, L)).astype(np.float32)
+    kw, _, _ = load_golden("c1_am")
+    got = _plan(kw).rfft(_dev(x, gpu), n).cpu().numpy()
+    want = O.rfft_rows(x, n)
+    assert got.shape == want.shape == (37, n // 2 + 1)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-6 * scale * np.log2(n)
+
+
+def test_modspec_matches_oracle(gpu):
+    kw, y, exp = load_golden("c1_am")
+    plan = _plan(kw)
+    m = plan.mfcc(_dev(y, gpu)[None, :])
+    ms = plan.modspec(m)[0].cpu().numpy()
+    want = exp["modspec"]
+    assert ms.shape == want.shape == (13, 65)
+    assert np.abs(ms - want).max() <= 1e-4 * np.abs(want).max()
+    # 10 s clip: T = 1001 -> n_mod 1024
+    y10 = O.synth_clip(11, 160000, 16000, "am")
+    m10 = plan.mfcc(_dev(y10, gpu)[None, :])
+    ms10 = plan.modspec(m10)[0].cpu().numpy()
+    want10 = O.modspec(O.mfcc(y10, O.OracleConfig(**kw)))
+    assert ms10.shape == (13, 513)
+    assert np.abs(ms10 - want10).max() <= 1e-4 * np.abs(want10).max()
+
+
+def test_full_size_properties(gpu):
+    """BASELINE configs[1] shape (1024 x 10 s): properties that need no oracle at full size."""
+    import torch
+    kw, _, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    g = torch.Generator(device=gpu).manual_seed(0)
+    B, n = 1024, 160000
+    t = torch.arange(n, device=gpu, dtype=torch.float32) / 16000.0
+    base = 0.3 * torch.sin(2 * np.pi * 220 * t) * (1 + 0.5 * torch.sin(2 * np.pi * 4 * t))
+    audio = base[None, :] + 0.05 * torch.randn((B, n), generator=g, device=gpu)
+    m = plan.mfcc(audio)
+    assert m.shape == (B, 13, 1001) and bool(torch.isfinite(m).all())
+    # (1) spot clips agree with the oracle
+    for i in (0, 511, 1023):
+        mfcc_close(m[i].cpu().numpy(), O.mfcc(audio[i].cpu().numpy(), O.OracleConfig(**kw)), f"clip {i}")
+    # (2) permutation equivariance over the batch, bit-exact
+    perm = torch.randperm(B, device=gpu, generator=g)
+    assert torch.equal(plan.mfcc(audio[perm].contiguous()), m[perm])
+    # (3) gain invariance: scaling the input by g shifts c0 by sqrt(n_mels)*20*log10(g), leaves c1.. alone
+    m2 = plan.mfcc(audio[:8] * 4.0)
+    shift = np.sqrt(kw["n_mels"]) * 20 * np.log10(4.0)
+    assert torch.allclose(m2[:, 0], m[:8, 0] + shift, atol=2e-2)
+    assert torch.allclose(m2[:, 1:], m[:8, 1:], atol=2e-2)
+    # (4) Parseval on the trajectory rFFT
+    ms = plan.modspec(m)
+    assert ms.shape == (B, 13, 513)
+    e_time = (m.double() ** 2).sum(-1)
+    w = torch.full((513,), 2.0, device=gpu, dtype=torch.float64)
+    w[0] = w[-1] = 1.0
+    e_freq = ((ms.real.double() ** 2 + ms.imag.double() ** 2) * w).sum(-1) / 1024
+    assert torch.allclose(e_time, e_freq, rtol=1e-4)
+
+
+def test_drop_in_get_MFCCS_change(gpu):
+    from modulation_mfcc_amd import get_MFCCS_change
+    kw, y, exp = load_golden("refdefault_am")
+    tot, T = get_MFCCS_change(y, 10000, channelN=0, tStep=0.005, winLen=0.025, n_mfcc=13, n_fft=512,
+                              minFreq=100, maxFreq=10000, removeFirst=1, filtCutoff=12, filtOrd=6,
+                              diffMethod="grad", outFilter="iir", outFiltType="low", outFiltCutOff=[12],
+                              outFiltLen=6, outFiltPolyOrd=3)
+    np.testing.assert_array_equal(T, exp["T"])
+    assert tot.dtype == np.float64 and tot.shape == exp["totChange"].shape
+    assert np.abs(tot - exp["totChange"]).max() <= 1e-4 * np.abs(exp["totChange"]).max()
+    # stereo array + channel pick, float64 input (script/mfcc.py:377-380)
+    st = np.stack([y.astype(np.float64), np.zeros_like(y, dtype=np.float64)])
+    tot2, _ = get_MFCCS_change(st, 10000, channelN=0, tStep=0.005, outFiltCutOff=[12])
+    np.testing.assert_allclose(tot2, tot, rtol=1e-12)
+
+
+def test_error_behaviour(gpu):
+    import torch
+    kw, y, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    with pytest.raises(TypeError):
+        plan.mfcc(torch.zeros(100))                        # host tensor
+    with pytest.raises(TypeError):
+        plan.mfcc(torch.zeros(100, dtype=torch.float64, device=gpu))
+    with pytest.raises(ValueError):
+        plan.rfft(torch.zeros((2, 600), device=gpu), 512)  # row longer than n
+    with pytest.raises(NotImplementedError):
+        plan.rfft(torch.zeros((2, 100), device=gpu), 500)
