@@ -22,7 +22,7 @@
 
 #include "mm_internal.h"
 
-#define MM_TW_N 8192  // master twiddle table: exp(-2 pi i k / 8192), k < 4096
+#define MM_TW_N 8192  // master twiddle table: exp(-2 pi i k / 8192), k < 8192 (full circle)
 
 static thread_local std::string g_hip_err;
 
@@ -257,6 +257,8 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
   }
 }
 
+#include "mm_fft16.hip.inc"
+
 // ------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------
@@ -425,7 +427,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   }
   std::vector<float> win(cfg->n_fft), mel((size_t)cfg->n_mels * p->n_bins),
       dct((size_t)cfg->n_mfcc * cfg->n_mels), dct_t((size_t)cfg->n_mels * p->kp, 0.0f),
-      tw(MM_TW_N);
+      tw(2 * MM_TW_N);
   mm::build_window(*cfg, win.data());
   mm::build_mel(*cfg, mel.data());
   mm::build_dct(*cfg, dct.data());
@@ -572,6 +574,22 @@ static int launch_rfft(mm_plan* p, const float* d_in, int64_t rows, int64_t in_l
   RfftParams q;
   q.in = d_in; q.rows = rows; q.in_len = in_len; q.in_stride = in_stride; q.n = n;
   q.log2nc = ilog2(n) - 1; q.rows_per_wave = 4; q.tw = p->d_tw; q.out = d_out;
+  if (!p->force_generic && (n == 512 || n == 1024)) {
+    const int rows_per_wave = (n == 512) ? 4 : 2;
+    const int64_t groups = (rows + rows_per_wave - 1) / rows_per_wave;
+    int64_t grid = (groups + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    const bool fast = (in_len == n) && (in_stride % 2 == 0) && (((uintptr_t)d_in & 7) == 0);
+    if (n == 512) {
+      if (fast) hipLaunchKernelGGL((rfft16_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, st, q);
+      else hipLaunchKernelGGL((rfft16_kernel<1, false>), dim3((unsigned)grid), dim3(256), 0, st, q);
+    } else {
+      if (fast) hipLaunchKernelGGL((rfft16_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, st, q);
+      else hipLaunchKernelGGL((rfft16_kernel<2, false>), dim3((unsigned)grid), dim3(256), 0, st, q);
+    }
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
   const int nc = n / 2;
   const int64_t grid = (rows + 4 * q.rows_per_wave - 1) / (4 * q.rows_per_wave);
   if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;

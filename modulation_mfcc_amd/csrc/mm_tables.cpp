@@ -98,9 +98,9 @@ void build_dct(const mm_config& c, float* out) {
   }
 }
 
-// tw[k] = exp(-2 pi i k / n), k < n/2, float2 interleaved
+// tw[k] = exp(-2 pi i k / n), k < n (full circle), float2 interleaved
 void build_twiddles(int n, float* out) {
-  for (int k = 0; k < n / 2; ++k) {
+  for (int k = 0; k < n; ++k) {
     const double a = -2.0 * kPi * (double)k / (double)n;
     out[2 * k] = (float)std::cos(a);
     out[2 * k + 1] = (float)std::sin(a);
