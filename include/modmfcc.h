@@ -93,6 +93,17 @@ int32_t mm_mod_fft_len(const mm_config* cfg, int64_t n_frames);  /* resolved n_m
 int mm_build_window(const mm_config* cfg, float* out /*[n_fft]*/);
 int mm_build_mel(const mm_config* cfg, float* out /*[n_mels][n_fft/2+1]*/);
 int mm_build_dct(const mm_config* cfg, float* out /*[n_mfcc][n_mels]*/);
+/* Sweep form of the mel matrix used by the lane<->frame kernels (host-only, for tests): bin k
+ * feeds filter d[k] with weight wlo[k] and filter d[k]+1 with weight whi[k]; part = per-wave
+ * {k_begin, k_end, m_begin, m_end}.  Returns MM_ERR_UNSUPPORTED if the matrix has another shape. */
+int mm_build_mel_sweep(const mm_config* cfg, int n_waves, float* wlo /*[n_bins]*/,
+                       float* whi /*[n_bins]*/, int32_t* d /*[n_bins]*/, int32_t* part /*[n_waves][4]*/);
+/* Run form of the same sweep, exactly as the fused kernel reads it from LDS (host-only, for tests):
+ * hdr [n_runs][4] = {first bin (multiple of 4), n_groups, first group, filter d}; grp [n_groups][8] =
+ * {weight in filter d x4, weight in filter d+1 x4}; part [n_waves][4] = {run_begin, run_end, m_begin,
+ * m_end}.  counts[0] = n_runs, counts[1] = n_groups.  Capacities are in runs / groups. */
+int mm_build_mel_runs(const mm_config* cfg, int n_waves, int32_t* hdr, int32_t hdr_cap, float* grp,
+                      int32_t grp_cap, int32_t* part, int32_t* counts);
 /* Butterworth low-pass as second-order sections, scipy.signal.butter(order, wn, 'low',
  * output='sos') layout [n_sections][6]; returns the number of sections or a negative status. */
 int mm_build_butter_sos(int order, double wn, double* sos /*[(order+1)/2][6]*/);

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "mm_build_window": (C.c_int, [_cfgp, _vp]),
     "mm_build_mel": (C.c_int, [_cfgp, _vp]),
     "mm_build_dct": (C.c_int, [_cfgp, _vp]),
+    "mm_build_mel_sweep": (C.c_int, [_cfgp, C.c_int, _vp, _vp, _vp, _vp]),
+    "mm_build_mel_runs": (C.c_int, [_cfgp, C.c_int, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp]),
     "mm_build_butter_sos": (C.c_int, [C.c_int, C.c_double, _vp]),
     "mm_plan_create": (C.c_int, [_cfgp, C.POINTER(_vp)]),
     "mm_plan_destroy": (C.c_int, [_vp]),

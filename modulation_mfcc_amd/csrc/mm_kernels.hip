@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -276,6 +277,11 @@ struct mm_plan {
   int *d_mel_start, *d_mel_len, *d_mel_off;
   float* d_mel_w;
   float* d_dct_t;
+  float* d_sw_tab;             // mel run table of the fused kernel (headers + groups)
+  int* d_sw_part;
+  int sw_n_runs, sw_n_tab16;
+  size_t lm_lds_bytes;
+  int num_cus;
   // timing
   int timing_on;
   std::vector<hipEvent_t> ev_pool;  // pairs
@@ -398,6 +404,39 @@ int mm_build_dct(const mm_config* c, float* out) {
   mm::build_dct(*c, out);
   return MM_OK;
 }
+int mm_build_mel_sweep(const mm_config* c, int n_waves, float* wlo, float* whi, int32_t* d, int32_t* part) {
+  int s = mm::validate(c);
+  if (s) return s;
+  if (n_waves < 1 || !wlo || !whi || !d || !part) return MM_ERR_INVALID_ARG;
+  std::vector<float> mel((size_t)c->n_mels * (c->n_fft / 2 + 1));
+  mm::build_mel(*c, mel.data());
+  mm::MelSweep sw;
+  if (!mm::build_mel_sweep(*c, mel.data(), n_waves, &sw)) return MM_ERR_UNSUPPORTED;
+  std::memcpy(wlo, sw.wlo.data(), sw.wlo.size() * 4);
+  std::memcpy(whi, sw.whi.data(), sw.whi.size() * 4);
+  std::memcpy(d, sw.d.data(), sw.d.size() * 4);
+  std::memcpy(part, sw.part.data(), sw.part.size() * 4);
+  return MM_OK;
+}
+int mm_build_mel_runs(const mm_config* c, int n_waves, int32_t* hdr, int32_t hdr_cap, float* grp,
+                      int32_t grp_cap, int32_t* part, int32_t* counts) {
+  int s = mm::validate(c);
+  if (s) return s;
+  if (n_waves < 1 || !hdr || !grp || !part || !counts) return MM_ERR_INVALID_ARG;
+  std::vector<float> mel((size_t)c->n_mels * (c->n_fft / 2 + 1));
+  mm::build_mel(*c, mel.data());
+  mm::MelSweep sw;
+  if (!mm::build_mel_sweep(*c, mel.data(), n_waves, &sw)) return MM_ERR_UNSUPPORTED;
+  mm::MelRuns r;
+  mm::build_mel_runs(*c, sw, n_waves, &r);
+  counts[0] = (int32_t)(r.hdr.size() / 4);
+  counts[1] = (int32_t)(r.grp.size() / 8);
+  if (counts[0] > hdr_cap || counts[1] > grp_cap) return MM_ERR_WORKSPACE;
+  std::memcpy(hdr, r.hdr.data(), r.hdr.size() * 4);
+  std::memcpy(grp, r.grp.data(), r.grp.size() * 4);
+  std::memcpy(part, r.part.data(), r.part.size() * 4);
+  return MM_OK;
+}
 int mm_build_butter_sos(int order, double wn, double* sos) { return mm::build_butter_sos(order, wn, sos); }
 
 int mm_plan_create(const mm_config* cfg, mm_plan** out) {
@@ -420,6 +459,8 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   std::memset(p->t_cnt, 0, sizeof(p->t_cnt));
   p->d_window = nullptr; p->d_tw = nullptr; p->d_mel_start = p->d_mel_len = p->d_mel_off = nullptr;
   p->d_mel_w = nullptr; p->d_dct_t = nullptr;
+  p->d_sw_tab = nullptr; p->d_sw_part = nullptr;
+  p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
     g_hip_err = "hipGetDevice failed (no GPU?)";
     delete p;
@@ -447,6 +488,35 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     mm_plan_destroy(p);
     return rc;
   }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
+      p->num_cus = prop.multiProcessorCount;
+  }
+  // register radix-16 path: n_fft 512, even hop (8-byte frame loads), no pre-emphasis
+  mm::MelSweep sw;
+  if (cfg->n_fft == 512 && (cfg->hop_length % 2) == 0 && cfg->preemph == 0.0f &&
+      mm::build_mel_sweep(*cfg, mel.data(), 8, &sw)) {
+    mm::MelRuns runs;
+    mm::build_mel_runs(*cfg, sw, 8, &runs);
+    std::vector<float> tab(runs.hdr.size() + runs.grp.size());
+    std::memcpy(tab.data(), runs.hdr.data(), runs.hdr.size() * 4);
+    std::memcpy(tab.data() + runs.hdr.size(), runs.grp.data(), runs.grp.size() * 4);
+    p->sw_n_runs = (int)(runs.hdr.size() / 4);
+    p->sw_n_tab16 = (int)(tab.size() / 4);
+    p->lm_lds_bytes = (size_t)MM_LM_TAB_OFF + tab.size() * 4;
+    if (p->lm_lds_bytes > MM_LM_LDS_MAX) { *out = p; return MM_OK; }   // stays on the generic path
+    if ((rc = upload(&p->d_sw_tab, tab.data(), tab.size() * 4)) ||
+        (rc = upload(&p->d_sw_part, runs.part.data(), runs.part.size() * 4))) {
+      mm_plan_destroy(p);
+      return rc;
+    }
+    if (hipFuncSetAttribute((const void*)logmel512_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)p->lm_lds_bytes) == hipSuccess &&
+        hipFuncSetAttribute((const void*)logmel512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)p->lm_lds_bytes) == hipSuccess)
+      p->path = 1;
+  }
   *out = p;
   return MM_OK;
 }
@@ -456,6 +526,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_window); (void)hipFree(p->d_tw); (void)hipFree(p->d_mel_start);
   (void)hipFree(p->d_mel_len); (void)hipFree(p->d_mel_off); (void)hipFree(p->d_mel_w);
   (void)hipFree(p->d_dct_t);
+  (void)hipFree(p->d_sw_tab); (void)hipFree(p->d_sw_part);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
   return MM_OK;
@@ -485,6 +556,26 @@ size_t mm_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_samples) {
 static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch, int64_t n_samples,
                        int64_t stride, float* out_power, float* out_logmel, int* clip_key,
                        hipStream_t st) {
+  if (p->path == 1 && !p->force_generic && (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 &&
+      n_samples >= 2) {
+    Logmel512Params q;
+    q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
+    q.n_frames = mm_num_frames(&p->cfg, n_samples);
+    q.tiles_per_clip = (q.n_frames + 63) / 64;
+    q.n_tiles = batch * q.tiles_per_clip;
+    q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
+    q.window = p->d_window; q.tw = p->d_tw; q.mel_tab = (const float4*)p->d_sw_tab; q.n_runs = p->sw_n_runs; q.n_tab16 = p->sw_n_tab16;
+    q.wave_part = p->d_sw_part; q.out_logmel = out_logmel; q.clip_key = clip_key;
+    q.out_power = out_power;
+    q.dbg = getenv("MM_DEBUG") ? atoi(getenv("MM_DEBUG")) : 0;
+    const int64_t grid = q.n_tiles < p->num_cus ? q.n_tiles : p->num_cus;
+    if (mode == 0)
+      hipLaunchKernelGGL(logmel512_kernel<0>, dim3((unsigned)grid), dim3(512), p->lm_lds_bytes, st, q);
+    else
+      hipLaunchKernelGGL(logmel512_kernel<1>, dim3((unsigned)grid), dim3(512), p->lm_lds_bytes, st, q);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
   StftParams q;
   q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
   q.n_frames = mm_num_frames(&p->cfg, n_samples);

@@ -206,4 +206,120 @@ void build_mel_csr(const mm_config& c, const float* dense, MelCsr* csr) {
   if (csr->w.empty()) csr->w.push_back(0.0f);
 }
 
+// Returns false when the matrix does not have the <= 2 adjacent filters per bin structure
+// (cannot happen for triangular filters with shared edges; checked anyway).
+bool build_mel_sweep(const mm_config& c, const float* dense, int n_waves, MelSweep* out) {
+  const int n_mels = c.n_mels, n_bins = c.n_fft / 2 + 1;
+  out->wlo.assign(n_bins, 0.0f);
+  out->whi.assign(n_bins, 0.0f);
+  out->d.assign(n_bins, -1);
+  int prev = -1;
+  for (int k = 0; k < n_bins; ++k) {
+    int nz[3], cnt = 0;
+    for (int m = 0; m < n_mels && cnt < 3; ++m)
+      if (dense[(size_t)m * n_bins + k] != 0.0f) nz[cnt++] = m;
+    int d = prev;
+    if (cnt == 1) {
+      const int m = nz[0];
+      if (m - 1 >= prev) { d = m - 1; out->whi[k] = dense[(size_t)m * n_bins + k]; }
+      else if (m >= prev) { d = m; out->wlo[k] = dense[(size_t)m * n_bins + k]; }
+      else return false;
+    } else if (cnt == 2) {
+      if (nz[1] != nz[0] + 1 || nz[0] < prev) return false;
+      d = nz[0];
+      out->wlo[k] = dense[(size_t)nz[0] * n_bins + k];
+      out->whi[k] = dense[(size_t)nz[1] * n_bins + k];
+    } else if (cnt > 2) {
+      return false;
+    }
+    out->d[k] = d;
+    prev = d;
+  }
+  // partition the filters over the waves: cost = bins swept + 6 per emitted filter
+  auto range_of = [&](int m0, int m1, int* kb, int* ke) {
+    int b = n_bins, e = 0;
+    for (int k = 0; k < n_bins; ++k)
+      if (out->d[k] >= m0 - 1 && out->d[k] <= m1 - 1 && (out->wlo[k] != 0.0f || out->whi[k] != 0.0f)) {
+        b = std::min(b, k);
+        e = std::max(e, k + 1);
+      }
+    if (b >= e) { b = 0; e = 0; }
+    *kb = b; *ke = e;
+  };
+  int kb_all, ke_all;
+  range_of(0, n_mels, &kb_all, &ke_all);
+  const double total = (double)(ke_all - kb_all) + 6.0 * n_mels;
+  out->part.assign((size_t)n_waves * 4, 0);
+  int m = 0;
+  for (int w = 0; w < n_waves; ++w) {
+    const int m0 = m;
+    int m1 = m0;
+    if (w == n_waves - 1) {
+      m1 = n_mels;
+    } else {
+      const double target = total * (w + 1) / n_waves;
+      // advance while the cumulative cost of [0, m1) stays below the target
+      while (m1 < n_mels) {
+        int kb, ke;
+        range_of(0, m1 + 1, &kb, &ke);
+        const double cum = (double)(ke - kb_all > 0 ? ke - kb_all : 0) + 6.0 * (m1 + 1);
+        if (cum > target && m1 > m0) break;
+        ++m1;
+        if (cum > target) break;
+      }
+      const int left_waves = n_waves - 1 - w;
+      if (n_mels - m1 < left_waves) m1 = std::max(m0, n_mels - left_waves);  // keep >= 1 each if possible
+    }
+    int kb, ke;
+    range_of(m0, m1, &kb, &ke);
+    if (m1 <= m0) { kb = 0; ke = 0; }
+    out->part[w * 4 + 0] = kb;
+    out->part[w * 4 + 1] = ke;
+    out->part[w * 4 + 2] = m0;
+    out->part[w * 4 + 3] = m1;
+    m = m1;
+  }
+  return true;
+}
+
+void build_mel_runs(const mm_config& c, const MelSweep& sw, int n_waves, MelRuns* out) {
+  const int n_bins = c.n_fft / 2 + 1;
+  out->hdr.clear(); out->grp.clear();
+  out->part.assign((size_t)n_waves * 4, 0);
+  for (int w = 0; w < n_waves; ++w) {
+    const int m0 = sw.part[w * 4 + 2], m1 = sw.part[w * 4 + 3];
+    out->part[w * 4 + 0] = (int)(out->hdr.size() / 4);
+    out->part[w * 4 + 2] = m0;
+    out->part[w * 4 + 3] = m1;
+    if (m1 > m0) {
+      for (int d = m0 - 1; d <= m1 - 1; ++d) {
+        int ks = n_bins, ke = 0;
+        for (int k = 0; k < n_bins; ++k)
+          if (sw.d[k] == d && (sw.wlo[k] != 0.0f || sw.whi[k] != 0.0f)) { ks = std::min(ks, k); ke = std::max(ke, k + 1); }
+        int g0 = 0, g1 = 0;
+        if (ke > ks) { g0 = ks / 4; g1 = (ke + 3) / 4; }
+        out->hdr.push_back(4 * g0);
+        out->hdr.push_back(g1 - g0);
+        out->hdr.push_back((int)(out->grp.size() / 8));
+        out->hdr.push_back(d);
+        for (int g = g0; g < g1; ++g) {
+          float wl[4], wh[4];
+          for (int u = 0; u < 4; ++u) {
+            const int k = 4 * g + u;
+            const bool in = (k >= ks && k < ke && k < n_bins && sw.d[k] == d);
+            wl[u] = in ? sw.wlo[k] : 0.0f;
+            wh[u] = in ? sw.whi[k] : 0.0f;
+            // filter m0-1 (first run) and filter m1 (last run) belong to other waves
+            if (d == m0 - 1) wl[u] = 0.0f;
+            if (d == m1 - 1) wh[u] = 0.0f;
+          }
+          for (int u = 0; u < 4; ++u) out->grp.push_back(wl[u]);
+          for (int u = 0; u < 4; ++u) out->grp.push_back(wh[u]);
+        }
+      }
+    }
+    out->part[w * 4 + 1] = (int)(out->hdr.size() / 4);
+  }
+}
+
 }  // namespace mm

@@ -88,6 +88,30 @@ class MfccConfig:
         _lib.check(_lib.load().mm_build_dct(C.byref(c), out.ctypes.data), "mm_build_dct")
         return out
 
+    def mel_sweep(self, n_waves: int = 8):
+        """(wlo, whi, d, part): the sweep form of the mel matrix the fused kernel walks."""
+        c = self.to_c()
+        wlo = np.empty(self.n_bins, dtype=np.float32)
+        whi = np.empty(self.n_bins, dtype=np.float32)
+        d = np.empty(self.n_bins, dtype=np.int32)
+        part = np.empty((n_waves, 4), dtype=np.int32)
+        _lib.check(_lib.load().mm_build_mel_sweep(C.byref(c), n_waves, wlo.ctypes.data, whi.ctypes.data,
+                                                  d.ctypes.data, part.ctypes.data), "mm_build_mel_sweep")
+        return wlo, whi, d, part
+
+    def mel_runs(self, n_waves: int = 8):
+        """(hdr [n_runs,4], grp [n_groups,8], part [n_waves,4]): the LDS tables of the fused kernel."""
+        c = self.to_c()
+        cap_r, cap_g = self.n_mels + 2 * n_waves + 8, self.n_bins // 4 + 2 * self.n_mels + 4 * n_waves + 8
+        hdr = np.zeros((cap_r, 4), dtype=np.int32)
+        grp = np.zeros((cap_g, 8), dtype=np.float32)
+        part = np.zeros((n_waves, 4), dtype=np.int32)
+        cnt = np.zeros(2, dtype=np.int32)
+        _lib.check(_lib.load().mm_build_mel_runs(C.byref(c), n_waves, hdr.ctypes.data, cap_r,
+                                                 grp.ctypes.data, cap_g, part.ctypes.data,
+                                                 cnt.ctypes.data), "mm_build_mel_runs")
+        return hdr[:cnt[0]], grp[:cnt[1]], part
+
     def asdict(self):
         return asdict(self)
 

@@ -119,3 +119,70 @@ def test_package_does_not_import_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".cpp", ".h", ".inc")):
                 assert "oracle" not in open(os.path.join(dirpath, f)).read().lower().replace("# oracle", ""), f
+
+
+def _sweep_emulate(cfg, P, n_waves=8):
+    """Python emulation of phase B of logmel512_kernel (mm_fft16.hip.inc) on one power row."""
+    wlo, whi, d, part = cfg.mel_sweep(n_waves)
+    out = np.full(cfg.n_mels, np.nan)
+    for (kb, ke, m0, m1) in part:
+        A = B = 0.0
+        dd = m0 - 1
+        for k in range(kb, ke):
+            while dd < d[k]:
+                if m0 <= dd < m1:
+                    assert np.isnan(out[dd]); out[dd] = A
+                A, B, dd = B, 0.0, dd + 1
+            A += float(wlo[k]) * P[k]
+            B += float(whi[k]) * P[k]
+        while dd < m1:
+            if dd >= m0:
+                assert np.isnan(out[dd]); out[dd] = A
+            A, B, dd = B, 0.0, dd + 1
+    return out
+
+
+@pytest.mark.parametrize("kw", CFGS + [
+    dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=128, n_mfcc=13, fmin=0.0, fmax=8000.0),
+    dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=3, n_mfcc=2, fmin=300.0, fmax=3000.0),
+    dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=256, n_mfcc=13, fmin=0.0, fmax=8000.0),
+])
+def test_mel_sweep_equals_dense_matrix(kw):
+    c = MfccConfig(**kw)
+    W = c.mel_filterbank().astype(np.float64)
+    wlo, whi, d, part = c.mel_sweep(8)
+    assert (np.diff(d) >= 0).all() and d.min() >= -1 and d.max() <= c.n_mels - 1
+    # the sweep tables hold exactly the matrix entries
+    R = np.zeros_like(W)
+    for k in range(c.n_bins):
+        if wlo[k]:
+            R[d[k], k] = wlo[k]
+        if whi[k]:
+            R[d[k] + 1, k] = whi[k]
+    np.testing.assert_array_equal(R, W)
+    # the per-wave partition covers every filter exactly once, in order
+    assert part[0, 2] == 0 and part[-1, 3] == c.n_mels and (part[1:, 2] == part[:-1, 3]).all()
+    P = np.random.default_rng(3).uniform(0.0, 2.0, c.n_bins)
+    got = _sweep_emulate(c, P)
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(got, W @ P, rtol=1e-12, atol=1e-15)
+    # run form (what phase B of logmel512_kernel executes): emulate it on one padded power row
+    hdr, grp, rpart = c.mel_runs(8)
+    Pp = np.zeros(4 * ((c.n_bins + 3) // 4))
+    Pp[:c.n_bins] = P
+    out = np.full(c.n_mels, np.nan)
+    for (r0, r1, m0, m1) in rpart:
+        carry = 0.0
+        for (k4, ng, go, dd) in hdr[r0:r1]:
+            assert k4 % 4 == 0 and k4 + 4 * ng <= len(Pp)
+            sa = sb = 0.0
+            for g in range(ng):
+                pv = Pp[k4 + 4 * g:k4 + 4 * g + 4]
+                sa += float(grp[go + g, :4].astype(np.float64) @ pv)
+                sb += float(grp[go + g, 4:].astype(np.float64) @ pv)
+            if dd >= m0:
+                assert np.isnan(out[dd]) and dd < m1
+                out[dd] = carry + sa
+            carry = sb
+    assert not np.isnan(out).any()
+    np.testing.assert_allclose(out, W @ P, rtol=1e-12, atol=1e-15)

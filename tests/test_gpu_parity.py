@@ -82,13 +82,15 @@ def test_batch_rows_are_independent_and_strided(gpu):
     clips = np.stack([O.synth_clip(100 + i, n, kw["sr"], k) for i, k in
                       enumerate(["am", "noise", "silence", "quiet_tail", "chirp", "impulse", "am"])])
     plan = _plan(kw)
-    big = torch.zeros((clips.shape[0], n + 37), dtype=torch.float32, device=gpu)
-    big[:, :n] = _dev(clips, gpu)
-    got = plan.mfcc(big[:, :n]).cpu().numpy()          # non-contiguous rows (stride n+37)
-    for i in range(clips.shape[0]):
-        mfcc_close(got[i], O.mfcc(clips[i], cfg), f"clip {i}")
-    again = plan.mfcc(_dev(clips[3:4], gpu)).cpu().numpy()
-    np.testing.assert_array_equal(again[0], got[3])   # bit-identical regardless of batch position
+    for pad in (38, 37):                               # even row pitch: radix-16 path; odd: generic
+        big = torch.zeros((clips.shape[0], n + pad), dtype=torch.float32, device=gpu)
+        big[:, :n] = _dev(clips, gpu)
+        got = plan.mfcc(big[:, :n]).cpu().numpy()      # non-contiguous rows
+        for i in range(clips.shape[0]):
+            mfcc_close(got[i], O.mfcc(clips[i], cfg), f"clip {i} pad {pad}")
+        if pad == 38:
+            again = plan.mfcc(_dev(clips[3:4], gpu)).cpu().numpy()
+            np.testing.assert_array_equal(again[0], got[3])   # bit-identical at any batch position
 
 
 @pytest.mark.parametrize("n,L", [(512, 512), (1024, 1001), (2048, 2048), (64, 40), (4096, 4096), (256, 1)])
@@ -181,3 +183,21 @@ def test_error_behaviour(gpu):
         plan.rfft(torch.zeros((2, 600), device=gpu), 512)  # row longer than n
     with pytest.raises(NotImplementedError):
         plan.rfft(torch.zeros((2, 100), device=gpu), 500)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 159, 160, 161, 511, 513, 10239, 10241, 20481])
+def test_ragged_lengths_fast_and_generic(n, gpu):
+    """Odd / tiny / tile-boundary clip lengths: edge masking of the radix-16 kernel == generic == oracle."""
+    kw, _, _ = load_golden("c1_am")
+    y = O.synth_clip(1000 + n, n, kw["sr"], "noise")
+    plan = _plan(kw)
+    fast = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
+    plan.force_generic(True)
+    try:
+        gen = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
+    finally:
+        plan.force_generic(False)
+    want = O.mfcc(y, O.OracleConfig(**kw))
+    assert fast.shape == want.shape == (13, 1 + n // 160)
+    mfcc_close(gen, want, f"generic n={n}")
+    mfcc_close(fast, want, f"radix16 n={n}")
