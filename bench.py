@@ -75,7 +75,7 @@ def cpu_baseline(clips_np, kw, with_mod, budget_s=12.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cores = max(1, min(cores, 16))   # a 1-GPU box's CPU share is 16 cores (the node shows 256)
     ctx = mp.get_context("fork")
     with ctx.Pool(cores, initializer=_cpu_init) as pool:
         pool.map(_cpu_one, [(clips_np[0], kw, with_mod)] * cores)           # warm-up / page-in
@@ -108,6 +108,7 @@ def main():
     import torch
     import torch.distributed as dist
     from modulation_mfcc_amd import MfccConfig, MfccPlan
+    from modulation_mfcc_amd.dist import SlabLayout, gather_slabs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -134,13 +135,10 @@ def main():
     audio = synth_batch(torch, dev, B, n, cfg.sr, seed0=1000 * rank)
 
     # one flat output slab per rank so that a single gather moves everything
-    n_mfcc_el = B * cfg.n_mfcc * T
-    n_mfcc_el += n_mfcc_el & 1
-    n_mod = cfg.mod_fft_len(T) if with_mod else 0
-    n_mod_el = B * cfg.n_mfcc * (n_mod // 2 + 1) * 2 if with_mod else 0
-    slab = torch.empty(n_mfcc_el + n_mod_el, dtype=torch.float32, device=dev)
-    mfcc_out = slab[:B * cfg.n_mfcc * T].view(B, cfg.n_mfcc, T)
-    mod_out = torch.view_as_complex(slab[n_mfcc_el:].view(B, cfg.n_mfcc, n_mod // 2 + 1, 2)) if with_mod else None
+    lay = SlabLayout.make(cfg, B, n, with_mod)
+    n_mod = lay.n_mod
+    slab = torch.empty(lay.numel, dtype=torch.float32, device=dev)
+    mfcc_out, mod_out = lay.views(slab)
     gathered = [torch.empty_like(slab) for _ in range(world)] if (world > 1 and rank == 0) else None
     plan.workspace(B, n)
 
@@ -149,7 +147,7 @@ def main():
         if with_mod:
             plan.modspec(mfcc_out, out=mod_out)
         if world > 1:
-            dist.gather(slab, gathered, dst=0)
+            gather_slabs(slab, dst=0, out=gathered)
 
     for _ in range(a.warmup):
         step()
