@@ -47,6 +47,13 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every
+// global load / store / atomic in flight: in the persistent fused kernels that exposes a full
+// memory round trip per tile (the next tile's prefetch before phase B, the log-mel stores after it).
+__device__ __forceinline__ void wg_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 }
 
 #include "mm_fft16.hip.inc"
+#include "mm_logmel16w.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 // plan
@@ -281,6 +289,10 @@ struct mm_plan {
   int* d_sw_part;
   int sw_n_runs, sw_n_tab16;
   size_t lm_lds_bytes;
+  float *d_w16_tab, *d_lane_tab;   // 16-wave variant: its own run table + per-lane records
+  int* d_w16_part;
+  int w16_n_runs, w16_n_tab16, w16_ok;
+  size_t w16_lds_bytes;
   int num_cus;
   // timing
   int timing_on;
@@ -460,6 +472,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_window = nullptr; p->d_tw = nullptr; p->d_mel_start = p->d_mel_len = p->d_mel_off = nullptr;
   p->d_mel_w = nullptr; p->d_dct_t = nullptr;
   p->d_sw_tab = nullptr; p->d_sw_part = nullptr;
+  p->d_w16_tab = p->d_lane_tab = nullptr; p->d_w16_part = nullptr; p->w16_ok = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
     g_hip_err = "hipGetDevice failed (no GPU?)";
@@ -516,6 +529,40 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         hipFuncSetAttribute((const void*)logmel512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)p->lm_lds_bytes) == hipSuccess)
       p->path = 1;
+    // 16-wave variant (4 waves per SIMD): needs its own 16-way mel partition and lane records
+    mm::MelSweep sw16;
+    if (p->path == 1 && mm::build_mel_sweep(*cfg, mel.data(), 16, &sw16)) {
+      mm::MelRuns r16;
+      mm::build_mel_runs(*cfg, sw16, 16, &r16);
+      std::vector<float> tab16(r16.hdr.size() + r16.grp.size());
+      std::memcpy(tab16.data(), r16.hdr.data(), r16.hdr.size() * 4);
+      std::memcpy(tab16.data() + r16.hdr.size(), r16.grp.data(), r16.grp.size() * 4);
+      p->w16_n_runs = (int)(r16.hdr.size() / 4);
+      p->w16_n_tab16 = (int)(tab16.size() / 4);
+      p->w16_lds_bytes = (size_t)MM_W16_TAB_OFF + tab16.size() * 4;
+      std::vector<float> lt(16 * MM_W16_LT_PITCH, 0.0f);
+      for (int q = 0; q < 16; ++q) {
+        float* r = lt.data() + q * MM_W16_LT_PITCH;
+        for (int n1 = 0; n1 < 16; ++n1) { r[2 * n1] = win[32 * n1 + 2 * q]; r[2 * n1 + 1] = win[32 * n1 + 2 * q + 1]; }
+        for (int k1 = 1; k1 < 16; ++k1) {
+          const int idx = (q * k1) * (MM_TW_N / 256);
+          r[32 + 2 * (k1 - 1)] = tw[2 * idx]; r[32 + 2 * (k1 - 1) + 1] = tw[2 * idx + 1];
+        }
+        for (int j = 0; j < 8; ++j) {
+          const int idx = (q + 16 * j) * (MM_TW_N / 512);
+          r[64 + 2 * j] = 0.5f * tw[2 * idx + 1]; r[64 + 2 * j + 1] = -0.5f * tw[2 * idx];
+        }
+      }
+      if (p->w16_lds_bytes <= MM_LM_LDS_MAX &&
+          upload(&p->d_w16_tab, tab16.data(), tab16.size() * 4) == MM_OK &&
+          upload(&p->d_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
+          upload(&p->d_w16_part, r16.part.data(), r16.part.size() * 4) == MM_OK &&
+          hipFuncSetAttribute((const void*)logmel512w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)p->w16_lds_bytes) == hipSuccess &&
+          hipFuncSetAttribute((const void*)logmel512w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)p->w16_lds_bytes) == hipSuccess)
+        p->w16_ok = 1;
+    }
   }
   *out = p;
   return MM_OK;
@@ -527,6 +574,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_mel_len); (void)hipFree(p->d_mel_off); (void)hipFree(p->d_mel_w);
   (void)hipFree(p->d_dct_t);
   (void)hipFree(p->d_sw_tab); (void)hipFree(p->d_sw_part);
+  (void)hipFree(p->d_w16_tab); (void)hipFree(p->d_lane_tab); (void)hipFree(p->d_w16_part);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
   return MM_OK;
@@ -568,7 +616,19 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.wave_part = p->d_sw_part; q.out_logmel = out_logmel; q.clip_key = clip_key;
     q.out_power = out_power;
     q.dbg = getenv("MM_DEBUG") ? atoi(getenv("MM_DEBUG")) : 0;
+    q.lane_tab = p->d_lane_tab;
     const int64_t grid = q.n_tiles < p->num_cus ? q.n_tiles : p->num_cus;
+    const bool use_w16 = p->w16_ok && !(getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 1);
+    if (use_w16) {
+      q.mel_tab = (const float4*)p->d_w16_tab; q.n_runs = p->w16_n_runs; q.n_tab16 = p->w16_n_tab16;
+      q.wave_part = p->d_w16_part;
+      if (mode == 0)
+        hipLaunchKernelGGL(logmel512w_kernel<0>, dim3((unsigned)grid), dim3(1024), p->w16_lds_bytes, st, q);
+      else
+        hipLaunchKernelGGL(logmel512w_kernel<1>, dim3((unsigned)grid), dim3(1024), p->w16_lds_bytes, st, q);
+      HIP_TRY(hipGetLastError());
+      return MM_OK;
+    }
     if (mode == 0)
       hipLaunchKernelGGL(logmel512_kernel<0>, dim3((unsigned)grid), dim3(512), p->lm_lds_bytes, st, q);
     else
