@@ -108,7 +108,7 @@ def main():
     import torch
     import torch.distributed as dist
     from modulation_mfcc_amd import MfccConfig, MfccPlan
-    from modulation_mfcc_amd.dist import SlabLayout, gather_slabs
+    from modulation_mfcc_amd.dist import PipelinedGather, SlabLayout
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -134,23 +134,31 @@ def main():
         plan.force_generic(True)
     audio = synth_batch(torch, dev, B, n, cfg.sr, seed0=1000 * rank)
 
-    # one flat output slab per rank so that a single gather moves everything
+    # one flat output slab per rank so that a single gather per step moves everything; with N > 1
+    # the slabs are double-buffered and the gather of step k runs on a side stream under the
+    # kernels of step k+1 (every step's gather still completes inside the timed region)
     lay = SlabLayout.make(cfg, B, n, with_mod)
     n_mod = lay.n_mod
-    slab = torch.empty(lay.numel, dtype=torch.float32, device=dev)
-    mfcc_out, mod_out = lay.views(slab)
-    gathered = [torch.empty_like(slab) for _ in range(world)] if (world > 1 and rank == 0) else None
+    pg = PipelinedGather(lay.numel, dev) if world > 1 else None
+    slab1 = torch.empty(lay.numel, dtype=torch.float32, device=dev) if world == 1 else None
     plan.workspace(B, n)
 
     def step():
+        slab = pg.acquire() if pg else slab1
+        mfcc_out, mod_out = lay.views(slab)
         plan.mfcc(audio, out=mfcc_out)
         if with_mod:
             plan.modspec(mfcc_out, out=mod_out)
-        if world > 1:
-            gather_slabs(slab, dst=0, out=gathered)
+        if pg:
+            pg.submit()
+
+    def drain():
+        if pg:
+            pg.finish()
 
     for _ in range(a.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -159,6 +167,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,7 +190,7 @@ def main():
                                f"n_fft {cfg.n_fft}, {cfg.n_mels} mel, {cfg.n_mfcc} MFCC"
                                + (f" + modulation spectrum (rFFT {n_mod} over trajectories)" if with_mod else ""),
                    "frames_per_clip": T, "clips_total": world * B, "kernel_path": plan.kernel_path,
-                   "parallelism": f"clips sharded x{world}" + (", one RCCL gather per step" if world > 1 else "")},
+                   "parallelism": f"clips sharded x{world}" + (", one RCCL gather per step (overlapped with the next step's kernels)" if world > 1 else "")},
     }
 
     if rank == 0:

@@ -79,6 +79,56 @@ def gather_slabs(slab, dst: int = 0, group=None, out=None):
     return None
 
 
+class PipelinedGather:
+    """Double-buffered gather on a side stream: the gather of batch k overlaps the kernels of
+    batch k+1 (xGMI fan-in into the root is slower than one batch of kernels at 8 GPUs).
+
+        pg = PipelinedGather(layout_numel, device)
+        for k in range(steps):
+            slab = pg.acquire()          # compute stream waits until slab's previous gather is done
+            ... launch kernels writing into slab on the current stream ...
+            pg.submit()                  # gather it on the side stream
+        pg.finish()                      # root: pg.received[i] = list of per-rank slabs of buffer i
+    """
+
+    def __init__(self, numel, device, dst=0, group=None, depth=2):
+        import torch
+        import torch.distributed as dist
+        self.dst, self.group, self.depth = dst, group, depth
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.slabs = [torch.empty(numel, dtype=torch.float32, device=device) for _ in range(depth)]
+        self.received = [[torch.empty(numel, dtype=torch.float32, device=device) for _ in range(self.world)]
+                         if self.rank == dst else None for _ in range(depth)]
+        self.stream = torch.cuda.Stream(device=device)
+        self.ev_done = [torch.cuda.Event() for _ in range(depth)]     # gather of buffer i finished
+        self.ev_ready = [torch.cuda.Event() for _ in range(depth)]    # kernels of buffer i finished
+        self.k = 0
+        self._used = [False] * depth
+
+    def acquire(self):
+        import torch
+        i = self.k % self.depth
+        if self._used[i]:
+            torch.cuda.current_stream().wait_event(self.ev_done[i])
+        return self.slabs[i]
+
+    def submit(self):
+        import torch
+        i = self.k % self.depth
+        self.ev_ready[i].record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(self.ev_ready[i])
+            gather_slabs(self.slabs[i], dst=self.dst, group=self.group, out=self.received[i])
+            self.ev_done[i].record(self.stream)
+        self._used[i] = True
+        self.k += 1
+
+    def finish(self):
+        import torch
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
 def mfcc_modspec_sharded(audio_all_or_local, cfg: MfccConfig, *, with_modspec=True, dst=0, group=None,
                          is_local=False, compute=None):
     """Run the hot path on this rank's clips and gather everything on ``dst``.
