@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 
 #include "mm_fft16.hip.inc"
 #include "mm_logmel16w.hip.inc"
+#include "mm_change.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 // plan
@@ -769,17 +770,68 @@ int mm_modspec_f32(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_fra
   return launch_rfft(p, d_mfcc, batch * p->cfg.n_mfcc, n_frames, n_frames, n, d_out, st);
 }
 
+// scipy.signal.sosfilt_zi + the padlen rule of sosfiltfilt, host side
+static int make_sosfilt(const double* sos, int n_sec, SosFilt* f) {
+  if (n_sec < 0 || n_sec > MM_MAX_SEC || (n_sec > 0 && !sos)) return MM_ERR_INVALID_ARG;
+  f->n_sec = n_sec;
+  f->padlen = 0;
+  if (n_sec == 0) return MM_OK;
+  double scale = 1.0;
+  int zb = 0, za = 0;
+  for (int s = 0; s < n_sec; ++s) {
+    const double* r = sos + 6 * s;
+    if (r[3] == 0.0) return MM_ERR_INVALID_ARG;
+    double b0 = r[0] / r[3], b1 = r[1] / r[3], b2 = r[2] / r[3], a1 = r[4] / r[3], a2 = r[5] / r[3];
+    f->c[s][0] = b0; f->c[s][1] = b1; f->c[s][2] = b2; f->c[s][3] = 1.0; f->c[s][4] = a1; f->c[s][5] = a2;
+    // lfilter_zi: (I - companion(a)^T) zi = b[1:] - a[1:] b0
+    const double B0 = b1 - a1 * b0, B1 = b2 - a2 * b0;
+    const double den = 1.0 + a1 + a2;
+    const double z0 = (B0 + B1) / den;
+    f->zi[s][0] = scale * z0;
+    f->zi[s][1] = scale * (B1 - a2 * z0);
+    scale *= (b0 + b1 + b2) / (1.0 + a1 + a2);
+    if (r[2] == 0.0) ++zb;
+    if (r[5] == 0.0) ++za;
+  }
+  const int ntaps = 2 * n_sec + 1 - (zb < za ? zb : za);
+  f->padlen = 3 * ntaps;
+  return MM_OK;
+}
+
+static int change_pads(int n_sec1, const double* sos1, int n_sec2, const double* sos2, SosFilt* f1, SosFilt* f2) {
+  int rc = make_sosfilt(sos1, n_sec1, f1);
+  if (rc) return rc;
+  if (n_sec1 < 1) return MM_ERR_INVALID_ARG;
+  return make_sosfilt(sos2, n_sec2, f2);
+}
+
 size_t mm_change_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_frames) {
-  (void)p; (void)batch; (void)n_frames;
-  return 0;
+  if (!p || batch < 1 || n_frames < 1) return 0;
+  // worst case padding: 3 * (2 * MM_MAX_SEC + 1) on both sides
+  const int64_t padmax = 3 * (2 * MM_MAX_SEC + 1);
+  const int64_t n = n_frames + 2 * padmax;
+  return (size_t)batch * ((size_t)p->cfg.n_mfcc * n + 2 * n) * sizeof(double);
 }
 
 int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_frames,
                        int32_t remove_first, const double* sos1, int32_t n_sec1, const double* sos2,
                        int32_t n_sec2, double* d_change, void* d_ws, size_t ws_bytes, void* stream) {
-  (void)p; (void)d_mfcc; (void)batch; (void)n_frames; (void)remove_first; (void)sos1; (void)n_sec1;
-  (void)sos2; (void)n_sec2; (void)d_change; (void)d_ws; (void)ws_bytes; (void)stream;
-  return MM_ERR_UNSUPPORTED;  // row N1: not built yet
+  if (!p || !d_mfcc || !d_change || !d_ws || batch < 1 || n_frames < 1) return MM_ERR_INVALID_ARG;
+  if (remove_first < 0 || remove_first >= p->cfg.n_mfcc) return MM_ERR_INVALID_ARG;
+  if (batch > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  ChangeParams q;
+  int rc = change_pads(n_sec1, sos1, n_sec2, sos2, &q.f1, &q.f2);
+  if (rc) return rc;
+  // scipy: "The length of the input vector x must be greater than padlen"
+  if (n_frames <= q.f1.padlen || n_frames <= q.f2.padlen) return MM_ERR_INVALID_ARG;
+  if (ws_bytes < mm_change_workspace_bytes(p, batch, n_frames)) return MM_ERR_WORKSPACE;
+  q.mfcc = d_mfcc; q.n_frames = n_frames; q.n_mfcc = p->cfg.n_mfcc; q.first_row = remove_first ? 1 : 0;
+  q.ws = (double*)d_ws; q.out = d_change;
+  hipStream_t st = (hipStream_t)stream;
+  StageTimer tm(p, MM_STAGE_CHANGE, st);
+  hipLaunchKernelGGL(mfcc_change_kernel, dim3((unsigned)batch), dim3(64), 0, st, q);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
 }
 
 int mm_timing_enable(mm_plan* p, int on) {

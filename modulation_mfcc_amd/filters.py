@@ -39,6 +39,23 @@ def _band_edges(cut, sr, kind):
     return np.asarray(cut, dtype=float) / (sr / 2)
 
 
+def _validate(filt, cutOff, filtType, sr):
+    if filt is None or cutOff is None:
+        raise Exception(_MSG_NO_CUTOFF if cutOff is None else _MSG_NO_FILT)
+    kind = _resolve_kind(filtType)
+    if any((sr / 2) <= np.array(cutOff)):
+        raise Exception(_MSG_NYQ)
+    if len(cutOff) > 0 and any(np.diff(cutOff) <= 0):
+        raise Exception(_MSG_ORDER)
+    return kind
+
+
+def iir_sos(sr, *, cutOff, filtLen=6, filtType="low"):
+    """The Butterworth sections applyFilter(filt='iir') would use (same checks, same exceptions)."""
+    kind = _validate("iir", cutOff, filtType, sr)
+    return _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
+
+
 def applyFilter(x, sr, /, *, filt: str = "iir", cutOff=[None], filtLen: int = 6,
                 filtType: str = "low", polyOrd: int = 3, coeffs=None):
     """Zero-phase low / high / band-pass of ``x`` (sampled at ``sr`` Hz).
@@ -52,13 +69,7 @@ def applyFilter(x, sr, /, *, filt: str = "iir", cutOff=[None], filtLen: int = 6,
 
     Raises the reference's bare ``Exception`` messages for the same bad arguments.
     """
-    if filt is None or cutOff is None:
-        raise Exception(_MSG_NO_CUTOFF if cutOff is None else _MSG_NO_FILT)
-    kind = _resolve_kind(filtType)
-    if any((sr / 2) <= np.array(cutOff)):
-        raise Exception(_MSG_NYQ)
-    if len(cutOff) > 0 and any(np.diff(cutOff) <= 0):
-        raise Exception(_MSG_ORDER)
+    kind = _validate(filt, cutOff, filtType, sr)
 
     if filt == "iir":
         sos = np.asarray(coeffs) if coeffs is not None else \

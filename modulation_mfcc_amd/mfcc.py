@@ -99,6 +99,19 @@ def get_MFCCS_change(audioIn, sigSr, /, *, channelN: int = 0, tStep: float = 0.0
 
     cfg = MfccConfig.from_reference_call(sigSr, tStep=tStep, winLen=winLen, n_mfcc=n_mfcc,
                                          n_fft=n_fft, minFreq=minFreq, maxFreq=maxFreq)
+    if _tail.device_path_applies(diffMethod, outFilter):
+        import torch
+        y = np.ascontiguousarray(np.asarray(signal), dtype=np.float32)
+        if y.ndim != 1:
+            raise ValueError("expected a 1-D signal")
+        plan = get_plan(cfg)
+        coeffs_dev = plan.mfcc(torch.from_numpy(y).to(plan.device))
+        anchors = _tail.time_anchors(coeffs_dev.shape[2], tStep, winLen)
+        change = _tail.mfcc_change_device(plan, coeffs_dev, tStep=tStep, removeFirst=removeFirst,
+                                          filtCutoff=filtCutoff, filtOrd=filtOrd, outFilter=outFilter,
+                                          outFiltType=outFiltType, outFiltCutOff=outFiltCutOff,
+                                          outFiltLen=outFiltLen)[0].cpu().numpy()
+        return change, anchors
     coeffs = mfcc_array(signal, cfg)
     anchors = _tail.time_anchors(coeffs.shape[1], tStep, winLen)
     change = _tail.mfcc_change(coeffs, tStep=tStep, removeFirst=removeFirst, filtCutoff=filtCutoff,

@@ -266,6 +266,32 @@ class MfccPlan:
                                             self._stream()), "mm_modspec_f32")
         return out
 
+    def mfcc_change(self, mfcc, sos1, sos2=None, remove_first=True):
+        """MFCC-change tail on the device (script/mfcc.py:392-427, diffMethod='grad'):
+        [B, n_mfcc, T] float32 -> [B, T] float64.  sos1 / sos2: SOS arrays [n_sec, 6] (host); sos2
+        None applies sos1 again (the reference's outFilter=None branch)."""
+        torch = _torch()
+        if not (isinstance(mfcc, torch.Tensor) and mfcc.is_cuda and mfcc.dtype == torch.float32
+                and mfcc.dim() == 3 and mfcc.shape[1] == self.cfg.n_mfcc):
+            raise TypeError("mfcc must be a float32 CUDA(HIP) tensor [B, n_mfcc, T]")
+        mfcc = mfcc.contiguous()
+        B, _, T = mfcc.shape
+        s1 = np.ascontiguousarray(np.asarray(sos1, dtype=np.float64).reshape(-1, 6))
+        s2 = s1 if sos2 is None else np.ascontiguousarray(np.asarray(sos2, dtype=np.float64).reshape(-1, 6))
+        for s in (s1, s2):
+            ntaps = 2 * s.shape[0] + 1 - min(int((s[:, 2] == 0).sum()), int((s[:, 5] == 0).sum()))
+            if T <= 3 * ntaps:   # scipy.signal.sosfiltfilt's own check and message
+                raise ValueError("The length of the input vector x must be greater than padlen, "
+                                 f"which is {3 * ntaps}.")
+        out = torch.empty((B, T), dtype=torch.float64, device=self.device)
+        need = int(self._lib.mm_change_workspace_bytes(self._h, B, T))
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.mm_mfcc_change_f64(self._h, mfcc.data_ptr(), B, T, 1 if remove_first else 0,
+                                                s1.ctypes.data, s1.shape[0], s2.ctypes.data, s2.shape[0],
+                                                out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                   "mm_mfcc_change_f64")
+        return out
+
     # ---- per-kernel device timing -------------------------------------------------------
     def timing_enable(self, on=True):
         _lib.check(self._lib.mm_timing_enable(self._h, 1 if on else 0), "mm_timing_enable")

@@ -201,3 +201,37 @@ def test_ragged_lengths_fast_and_generic(n, gpu):
     assert fast.shape == want.shape == (13, 1 + n // 160)
     mfcc_close(gen, want, f"generic n={n}")
     mfcc_close(fast, want, f"radix16 n={n}")
+
+
+@pytest.mark.parametrize("kwargs", [
+    dict(outFiltCutOff=[12]), dict(outFilter=None), dict(removeFirst=0, outFiltCutOff=[20]),
+    dict(filtOrd=5, filtCutoff=8, outFiltCutOff=[10], outFiltLen=3),
+    dict(outFiltType="band", outFiltCutOff=[2, 20]), dict(outFiltType="high", outFiltCutOff=[3]),
+])
+def test_change_tail_on_device(kwargs, gpu):
+    """Row N1: mm_mfcc_change_f64 against scipy's sosfiltfilt / gradient (the reference's tail)."""
+    from modulation_mfcc_amd import tail
+    kw, y, exp = load_golden("refdefault_am")
+    plan = _plan(kw)
+    m = _dev(np.stack([exp["mfcc"], exp["mfcc"][::-1].copy() * 0.5]), gpu)      # two "clips"
+    got = tail.mfcc_change_device(plan, m, tStep=0.005, **kwargs).cpu().numpy()
+    for i, mm in enumerate((exp["mfcc"], exp["mfcc"][::-1] * 0.5)):
+        want = O.mfcc_change_tail(mm.astype(np.float32), tStep=0.005, **kwargs)
+        assert got[i].shape == want.shape
+        # float64 recursion with poles close to the unit circle: fma contraction vs scipy's
+        # evaluation order moves results by ~5e-9 relative; tolerance 1e-7 of the curve's maximum
+        assert np.abs(got[i] - want).max() <= 1e-7 * np.abs(want).max()
+
+
+def test_change_tail_errors(gpu):
+    from modulation_mfcc_amd import get_MFCCS_change
+    kw, y, _ = load_golden("refdefault_am")
+    with pytest.raises(ValueError, match="greater than padlen"):
+        get_MFCCS_change(y[:500], 10000, tStep=0.005, outFiltCutOff=[12])    # 11 frames <= padlen 21
+    with pytest.raises(Exception, match="smaller than the half"):
+        get_MFCCS_change(y, 10000, tStep=0.005, outFiltCutOff=[100])
+    with pytest.raises(Exception, match="CutOff is None"):
+        get_MFCCS_change(y, 10000, tStep=0.005, outFiltCutOff=None)
+    # the reference's default outFiltCutOff=[None] dies inside numpy/scipy with a TypeError
+    with pytest.raises(TypeError):
+        get_MFCCS_change(y, 10000, tStep=0.005)
