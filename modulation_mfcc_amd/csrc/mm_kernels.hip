@@ -587,7 +587,11 @@ int mm_plan_config(const mm_plan* p, mm_config* out) {
   return MM_OK;
 }
 
-int mm_plan_kernel_path(const mm_plan* p) { return p ? (p->force_generic ? 0 : p->path) : MM_ERR_INVALID_ARG; }
+int mm_plan_kernel_path(const mm_plan* p) {
+  if (!p) return MM_ERR_INVALID_ARG;
+  if (p->force_generic) return 0;
+  return (p->path == 1 && p->w16_ok) ? 2 : p->path;
+}
 
 int mm_plan_force_generic(mm_plan* p, int on) {
   if (!p) return MM_ERR_INVALID_ARG;
