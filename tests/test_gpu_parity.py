@@ -29,31 +29,62 @@ def test_native_library_is_loaded(gpu):
     assert "libmodmfcc.so" in maps
 
 
-@pytest.mark.parametrize("generic", [False, True])
+class _variant:
+    """Select the fused-kernel variant for the calls inside: 'w16' (default where it applies), 'w8'
+    (MM_PATH=1: the 8-wave kernel, otherwise only used when the mel table is too big for w16) or
+    'generic'.  Configurations a variant does not cover fall through to the next one."""
+
+    def __init__(self, plan, which):
+        self.plan, self.which = plan, which
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("MM_PATH")
+        if self.which == "w8":
+            os.environ["MM_PATH"] = "1"
+        self.plan.force_generic(self.which == "generic")
+        return self
+
+    def __exit__(self, *a):
+        import os
+        self.plan.force_generic(False)
+        if self.old is None:
+            os.environ.pop("MM_PATH", None)
+        else:
+            os.environ["MM_PATH"] = self.old
+
+
+VARIANTS = ["w16", "w8", "generic"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
-def test_mfcc_matches_golden(name, generic, gpu):
+def test_mfcc_matches_golden(name, variant, gpu):
     kw, y, exp = load_golden(name)
     plan = _plan(kw)
-    plan.force_generic(generic)
-    try:
+    with _variant(plan, variant):
         got = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
-    finally:
-        plan.force_generic(False)
-    mfcc_close(got, exp["mfcc"], f"{name} generic={generic}")
+    mfcc_close(got, exp["mfcc"], f"{name} {variant}")
 
 
-@pytest.mark.parametrize("generic", [False, True])
-def test_stage_outputs_match_oracle(generic, gpu):
+def test_kernel_variants_selected(gpu):
+    kw, _, _ = load_golden("c1_am")
+    assert _plan(kw).kernel_path == "radix16-w16"
+    assert _plan(load_golden("refdefault_am")[0]).kernel_path == "radix16-w16"
+    assert _plan({**kw, "n_mels": 256}).kernel_path == "radix16-w8"      # mel table too big for w16
+    assert _plan(load_golden("c4_am")[0]).kernel_path == "generic"         # n_fft 2048
+    assert _plan(load_golden("ragged_preemph")[0]).kernel_path == "generic"  # odd hop + pre-emphasis
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_stage_outputs_match_oracle(variant, gpu):
     kw, y, exp = load_golden("c1_am")
     plan = _plan(kw)
-    plan.force_generic(generic)
-    try:
+    with _variant(plan, variant):
         d = _dev(y, gpu)[None, :]
         P = plan.stft_power(d)[0].cpu().numpy()
         lm, mx = plan.logmel(d)
         lm, mx = lm[0].cpu().numpy(), float(mx[0])
-    finally:
-        plan.force_generic(False)
     Pw = O.stft_power(y, kw["n_fft"], kw["hop_length"], kw["win_length"])
     assert P.shape == Pw.shape
     np.testing.assert_allclose(P, Pw, rtol=2e-4, atol=1e-5 * Pw.max())
@@ -61,6 +92,16 @@ def test_stage_outputs_match_oracle(generic, gpu):
     want = exp["logmel_unclamped"].T           # [n_mels, T]
     np.testing.assert_allclose(lm, want, rtol=0, atol=2e-3)
     assert mx == pytest.approx(float(want.max()), abs=2e-3)
+
+
+def test_many_mels_w8_kernel(gpu):
+    """n_mels = 256: 1-2 bin filters, empty filters, and the 8-wave kernel by default."""
+    kw, y, _ = load_golden("c1_am")
+    kw = {**kw, "n_mels": 256, "n_mfcc": 20, "fmin": 0.0}
+    plan = _plan(kw)
+    assert plan.kernel_path == "radix16-w8"
+    got = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
+    mfcc_close(got, O.mfcc(y, O.OracleConfig(**kw)), "n_mels 256")
 
 
 def test_clamp_path_is_exercised(gpu):
@@ -191,16 +232,12 @@ def test_ragged_lengths_fast_and_generic(n, gpu):
     kw, _, _ = load_golden("c1_am")
     y = O.synth_clip(1000 + n, n, kw["sr"], "noise")
     plan = _plan(kw)
-    fast = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
-    plan.force_generic(True)
-    try:
-        gen = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
-    finally:
-        plan.force_generic(False)
     want = O.mfcc(y, O.OracleConfig(**kw))
-    assert fast.shape == want.shape == (13, 1 + n // 160)
-    mfcc_close(gen, want, f"generic n={n}")
-    mfcc_close(fast, want, f"radix16 n={n}")
+    for variant in VARIANTS:
+        with _variant(plan, variant):
+            got = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
+        assert got.shape == want.shape == (13, 1 + n // 160)
+        mfcc_close(got, want, f"{variant} n={n}")
 
 
 @pytest.mark.parametrize("kwargs", [
