@@ -39,6 +39,22 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(stage):
+    """HBM bytes per launch of a stage's kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc.csv, written by tools/summarize_prof.py from separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes).  None if absent."""
+    import csv
+    import glob
+    key = {"logmel": "logmel512", "dct": "dct_clamp", "modspec": "rfft16_kernel<2", "rfft": "rfft16_kernel<1, true>"}.get(stage)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")))
+    if not key or not files:
+        return None, None
+    for r in csv.DictReader(open(files[-1])):
+        if key in r["Kernel"]:
+            return int(r["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def synth_batch(torch, device, batch, n, sr, seed0):
     """0.3 sin(2 pi 220 t)(1 + 0.5 sin(2 pi 4 t)) + 0.05 N(0,1), generated on device."""
     import math
@@ -206,8 +222,10 @@ def main():
         if dom in alg_bytes_per_frame:
             bytes_launch = alg_bytes_per_frame[dom] * B * T
             ach = bytes_launch / (per_stage[dom]["avg_ms"] * 1e-3) / 1e9
+            traffic, src = pmc_traffic(dom) if a.workload == "c3" else (None, None)
             res["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": src, "algorithmic_bytes_per_launch": bytes_launch,
                                "algorithmic_bytes_per_frame": alg_bytes_per_frame[dom],
                                "avg_launch_ms": per_stage[dom]["avg_ms"]}
 
