@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_fft16.hip.inc"
 #include "mm_logmel16w.hip.inc"
 #include "mm_change.hip.inc"
+#include "mm_fft2048.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 // plan
@@ -294,6 +295,8 @@ struct mm_plan {
   int* d_w16_part;
   int w16_n_runs, w16_n_tab16, w16_ok;
   size_t w16_lds_bytes;
+  float *d_k2_lane_tab, *d_k2_mel_lane;   // n_fft = 2048 wave-per-frame kernel
+  int k2_ok;
   int num_cus;
   // timing
   int timing_on;
@@ -474,6 +477,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_mel_w = nullptr; p->d_dct_t = nullptr;
   p->d_sw_tab = nullptr; p->d_sw_part = nullptr;
   p->d_w16_tab = p->d_lane_tab = nullptr; p->d_w16_part = nullptr; p->w16_ok = 0;
+  p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
     g_hip_err = "hipGetDevice failed (no GPU?)";
@@ -565,6 +569,58 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         p->w16_ok = 1;
     }
   }
+  // n_fft = 2048 wave-per-frame kernel: even hop, no pre-emphasis, n_mels <= 256, and the mel
+  // sweep must advance by at most one filter between consecutive bins of a lane's 16-bin slice
+  if (cfg->n_fft == 2048 && (cfg->hop_length % 2) == 0 && cfg->preemph == 0.0f && cfg->n_mels <= MM_K2_MAXMEL) {
+    mm::MelSweep sw2;
+    if (mm::build_mel_sweep(*cfg, mel.data(), 1, &sw2)) {
+      std::vector<float> ml(64 * 36, 0.0f);
+      bool ok = true;
+      for (int l = 0; l < 64 && ok; ++l) {
+        float* r = ml.data() + l * 36;
+        int dprev = sw2.d[16 * l];
+        int dstart = dprev;
+        unsigned bits = 0;
+        const int nslots = (l == 63) ? 17 : 16;
+        for (int i = 0; i < nslots; ++i) {
+          const int k = (i < 16) ? 16 * l + i : 1024;
+          const int adv = sw2.d[k] - dprev;
+          if (adv < 0 || adv > 1) { ok = false; break; }
+          if (adv == 1) bits |= (1u << i);
+          dprev = sw2.d[k];
+          r[i] = sw2.wlo[k];
+          r[17 + i] = sw2.whi[k];
+        }
+        std::memcpy(&r[34], &dstart, 4);
+        std::memcpy(&r[35], &bits, 4);
+      }
+      std::vector<float> lt(64 * MM_K2_LT_PITCH, 0.0f);
+      for (int l = 0; l < 64; ++l) {
+        float* r = lt.data() + l * MM_K2_LT_PITCH;
+        const int pq = l & 3;
+        for (int n1 = 0; n1 < 16; ++n1) { r[2 * n1] = win[128 * n1 + 2 * l]; r[2 * n1 + 1] = win[128 * n1 + 2 * l + 1]; }
+        for (int k1 = 1; k1 < 16; ++k1) {
+          const int i1 = ((l * k1) % 1024) * (MM_TW_N / 1024);   // W_1024^(n2*k1), n2 = lane
+          r[32 + 2 * (k1 - 1)] = tw[2 * i1]; r[32 + 2 * (k1 - 1) + 1] = tw[2 * i1 + 1];
+          const int i2 = ((pq * k1) % 64) * (MM_TW_N / 64);       // W_64^(p*j)
+          r[64 + 2 * (k1 - 1)] = tw[2 * i2]; r[64 + 2 * (k1 - 1) + 1] = tw[2 * i2 + 1];
+        }
+        for (int i = 0; i < 8; ++i) {
+          const int idx = (l + 64 * i) * (MM_TW_N / 2048);        // 0.5 * (-i) * W_2048^k
+          r[96 + 2 * i] = 0.5f * tw[2 * idx + 1]; r[96 + 2 * i + 1] = -0.5f * tw[2 * idx];
+        }
+      }
+      if (ok && upload(&p->d_k2_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
+          upload(&p->d_k2_mel_lane, ml.data(), ml.size() * 4) == MM_OK &&
+          hipFuncSetAttribute((const void*)logmel2048_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              MM_K2_LDS_BYTES) == hipSuccess &&
+          hipFuncSetAttribute((const void*)logmel2048_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              MM_K2_LDS_BYTES) == hipSuccess &&
+          hipFuncSetAttribute((const void*)dct_clamp_fm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              64 * (MM_K2_MAXMEL + 1) * 4) == hipSuccess)
+        p->k2_ok = 1;
+    }
+  }
   *out = p;
   return MM_OK;
 }
@@ -576,6 +632,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_dct_t);
   (void)hipFree(p->d_sw_tab); (void)hipFree(p->d_sw_part);
   (void)hipFree(p->d_w16_tab); (void)hipFree(p->d_lane_tab); (void)hipFree(p->d_w16_part);
+  (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
   return MM_OK;
@@ -590,6 +647,7 @@ int mm_plan_config(const mm_plan* p, mm_config* out) {
 int mm_plan_kernel_path(const mm_plan* p) {
   if (!p) return MM_ERR_INVALID_ARG;
   if (p->force_generic) return 0;
+  if (p->k2_ok) return 3;
   return (p->path == 1 && p->w16_ok) ? 2 : p->path;
 }
 
@@ -606,9 +664,32 @@ size_t mm_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_samples) {
   return align_up((size_t)batch * p->cfg.n_mels * T * 4, 256) + align_up((size_t)batch * 4, 256);
 }
 
+// frame_major: the caller accepts (and, where the n_fft = 2048 kernel runs, gets) log-mel rows laid out
+// [B][T][n_mels]; *is_fm reports which layout was written.
 static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch, int64_t n_samples,
                        int64_t stride, float* out_power, float* out_logmel, int* clip_key,
-                       hipStream_t st) {
+                       hipStream_t st, bool frame_major = false, bool* is_fm = nullptr) {
+  if (is_fm) *is_fm = false;
+  if (p->k2_ok && !p->force_generic && (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2) {
+    Logmel2048Params q;
+    q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
+    q.n_frames = mm_num_frames(&p->cfg, n_samples);
+    q.total_frames = batch * q.n_frames;
+    q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
+    q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane;
+    q.out_logmel = out_logmel; q.clip_key = clip_key; q.out_power = out_power;
+    if (frame_major) { q.sB = q.n_frames * q.n_mels; q.sT = q.n_mels; q.sM = 1; }
+    else { q.sB = q.n_frames * q.n_mels; q.sT = 1; q.sM = q.n_frames; }
+    if (is_fm) *is_fm = frame_major;
+    int64_t grid = (q.total_frames + MM_K2_WAVES - 1) / MM_K2_WAVES;
+    if (grid > p->num_cus) grid = p->num_cus;
+    if (mode == 0)
+      hipLaunchKernelGGL(logmel2048_kernel<0>, dim3((unsigned)grid), dim3(64 * MM_K2_WAVES), MM_K2_LDS_BYTES, st, q);
+    else
+      hipLaunchKernelGGL(logmel2048_kernel<1>, dim3((unsigned)grid), dim3(64 * MM_K2_WAVES), MM_K2_LDS_BYTES, st, q);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
   if (p->path == 1 && !p->force_generic && (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 &&
       n_samples >= 2) {
     Logmel512Params q;
@@ -705,21 +786,30 @@ int mm_mfcc_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_sampl
   const int64_t T = mm_num_frames(&p->cfg, n_samples);
   float* logmel = (float*)d_ws;
   int* keys = (int*)((char*)d_ws + align_up((size_t)batch * p->cfg.n_mels * T * 4, 256));
+  bool fm = false;
   {
     StageTimer tm(p, MM_STAGE_INIT, st);
     HIP_TRY(hipMemsetAsync(keys, 0x80, (size_t)batch * 4, st));
   }
   {
     StageTimer tm(p, MM_STAGE_LOGMEL, st);
-    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, nullptr, logmel, keys, st);
+    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, nullptr, logmel, keys, st, true, &fm);
     if (rc) return rc;
   }
   {
     StageTimer tm(p, MM_STAGE_DCT, st);
-    const int64_t bpc = (T + 255) / 256;
-    if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(dct_clamp_kernel, dim3((unsigned)(batch * bpc)), dim3(256), 0, st, logmel, keys,
-                       p->d_dct_t, d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
+    if (fm) {
+      const int64_t bpc = (T + 63) / 64;
+      if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+      hipLaunchKernelGGL(dct_clamp_fm_kernel, dim3((unsigned)(batch * bpc)), dim3(256),
+                         (size_t)64 * (p->cfg.n_mels + 1) * 4, st, logmel, keys, p->d_dct_t, d_mfcc, T,
+                         p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
+    } else {
+      const int64_t bpc = (T + 255) / 256;
+      if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+      hipLaunchKernelGGL(dct_clamp_kernel, dim3((unsigned)(batch * bpc)), dim3(256), 0, st, logmel, keys,
+                         p->d_dct_t, d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
+    }
     HIP_TRY(hipGetLastError());
   }
   return MM_OK;

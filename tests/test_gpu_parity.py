@@ -72,7 +72,7 @@ def test_kernel_variants_selected(gpu):
     assert _plan(kw).kernel_path == "radix16-w16"
     assert _plan(load_golden("refdefault_am")[0]).kernel_path == "radix16-w16"
     assert _plan({**kw, "n_mels": 256}).kernel_path == "radix16-w8"      # mel table too big for w16
-    assert _plan(load_golden("c4_am")[0]).kernel_path == "generic"         # n_fft 2048
+    assert _plan(load_golden("c4_am")[0]).kernel_path == "radix16-2048"    # n_fft 2048: wave-per-frame kernel
     assert _plan(load_golden("ragged_preemph")[0]).kernel_path == "generic"  # odd hop + pre-emphasis
 
 
@@ -92,6 +92,44 @@ def test_stage_outputs_match_oracle(variant, gpu):
     want = exp["logmel_unclamped"].T           # [n_mels, T]
     np.testing.assert_allclose(lm, want, rtol=0, atol=2e-3)
     assert mx == pytest.approx(float(want.max()), abs=2e-3)
+
+
+@pytest.mark.parametrize("n", [2, 479, 480, 1023, 1025, 4801, 24000, 30001])
+def test_nfft2048_kernel_vs_generic_and_oracle(n, gpu):
+    """C4-shaped config (48 kHz, n_fft 2048, 80 mel, 40 MFCC): wave-per-frame kernel == generic == oracle
+    on ragged lengths, incl. stage outputs."""
+    kw, _, _ = load_golden("c4_am")
+    y = O.synth_clip(2000 + n, n, kw["sr"], "am" if n > 5000 else "noise")
+    plan = _plan(kw)
+    assert plan.kernel_path == "radix16-2048"
+    d = _dev(np.stack([y, y[::-1].copy()]), gpu)
+    want = [O.mfcc(c, O.OracleConfig(**kw)) for c in (y, y[::-1])]
+    fast = plan.mfcc(d).cpu().numpy()
+    P = plan.stft_power(d).cpu().numpy()
+    lm, mx = plan.logmel(d)
+    with _variant(plan, "generic"):
+        gen = plan.mfcc(d).cpu().numpy()
+        Pg = plan.stft_power(d).cpu().numpy()
+        lmg, mxg = plan.logmel(d)
+    for i in range(2):
+        mfcc_close(gen[i], want[i], f"generic n={n}")
+        mfcc_close(fast[i], want[i], f"2048 n={n}")
+    np.testing.assert_allclose(P, Pg, rtol=2e-4, atol=1e-5 * max(Pg.max(), 1e-30))
+    np.testing.assert_allclose(lm.cpu().numpy(), lmg.cpu().numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(mx.cpu().numpy(), mxg.cpu().numpy(), rtol=0, atol=2e-3)
+
+
+def test_nfft2048_batch_determinism(gpu):
+    import torch
+    kw, _, _ = load_golden("c4_am")
+    plan = _plan(kw)
+    g = torch.Generator(device=gpu).manual_seed(3)
+    audio = 0.1 * torch.randn((37, 48000), generator=g, device=gpu)
+    m = plan.mfcc(audio)
+    perm = torch.randperm(37, device=gpu, generator=g)
+    assert torch.equal(plan.mfcc(audio[perm].contiguous()), m[perm])
+    for i in (0, 36):
+        mfcc_close(m[i].cpu().numpy(), O.mfcc(audio[i].cpu().numpy(), O.OracleConfig(**kw)), f"clip {i}")
 
 
 def test_many_mels_w8_kernel(gpu):
