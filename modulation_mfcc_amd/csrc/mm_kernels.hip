@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void dct_clamp_kernel(const float* __restrict_
     float acc[MM_DCT_KB];
 #pragma unroll
     for (int kk = 0; kk < MM_DCT_KB; ++kk) acc[kk] = 0.0f;
+#pragma unroll 4
     for (int m = 0; m < n_mels; ++m) {
       const float x = fmaxf(lm[(int64_t)m * n_frames], thr);
       const float* d = dct_t + (size_t)m * kp + k0;
