@@ -310,3 +310,46 @@ def test_change_tail_errors(gpu):
     # the reference's default outFiltCutOff=[None] dies inside numpy/scipy with a TypeError
     with pytest.raises(TypeError):
         get_MFCCS_change(y, 10000, tStep=0.005)
+
+
+def _random_cfgs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        n_fft = int(rng.choice([64, 128, 256, 512, 512, 512, 1024, 2048, 2048, 4096]))
+        win = int(rng.integers(max(2, n_fft // 4), n_fft + 1))
+        hop = int(rng.integers(1, max(2, win)))
+        if rng.random() < 0.5:
+            hop += hop & 1                      # even hops reach the radix-16 kernels
+        sr = int(rng.choice([8000, 10000, 16000, 22050, 44100, 48000]))
+        n_mels = int(rng.integers(2, min(129, n_fft // 2)))
+        n_mfcc = int(rng.integers(1, min(n_mels, 40) + 1))
+        fmin = float(rng.choice([0.0, 20.0, 100.0, 300.0]))
+        fmax = float(rng.choice([sr / 2, sr / 2 * 0.9, sr * 0.7, 3000.0]))
+        if fmax <= fmin + 50:
+            continue
+        out.append(dict(sr=sr, n_fft=n_fft, win_length=win, hop_length=max(1, hop), n_mels=n_mels, n_mfcc=n_mfcc,
+                        fmin=fmin, fmax=fmax, top_db=float(rng.choice([80.0, 40.0, -1.0])),
+                        preemph=float(rng.choice([0.0, 0.0, 0.97]))))
+    return out
+
+
+@pytest.mark.parametrize("idx", range(24))
+def test_random_configs_match_oracle(idx, gpu):
+    """Sweep of the configuration space (every kernel path, clamp on/off, pre-emphasis, filters
+    above Nyquist, odd hops and windows) against the oracle, two ragged clips per configuration."""
+    import warnings
+    kw = _random_cfgs(24, 20260)[idx]
+    rng = np.random.default_rng(idx)
+    plan = _plan(kw)
+    okw = dict(kw)
+    okw["top_db"] = None if kw["top_db"] < 0 else kw["top_db"]
+    n = int(rng.integers(kw["n_fft"] // 2, 6 * kw["n_fft"] + 7 * kw["hop_length"]))
+    clips = np.stack([O.synth_clip(50 + idx, n, kw["sr"], k) for k in ("am", "quiet_tail")])
+    got = plan.mfcc(_dev(clips, gpu)).cpu().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(2):
+            want = O.mfcc(clips[i], O.OracleConfig(**okw))
+            assert got[i].shape == want.shape
+            mfcc_close(got[i], want, f"cfg {idx} ({plan.kernel_path}) {kw} clip {i}")
