@@ -115,7 +115,8 @@ int mm_plan_config(const mm_plan* plan, mm_config* out);
 /* which fused STFT kernel mm_mfcc_f32 / mm_logmel_f32 / mm_stft_power_f32 use: 0 = generic LDS
  * radix-2, 1 = register radix-16, 8 waves per workgroup, 2 = register radix-16, 16 waves (n_fft 512,
  * even hop, no pre-emphasis; 2 needs the mel run table to fit beside the 154 KB of tiles in LDS),
- * 3 = register radix-16 wave-per-frame kernel for n_fft 2048 (even hop, no pre-emphasis) */
+ * 3 = register radix-16 wave-per-frame-group kernel (n_fft 1024 / 2048, or n_fft 512 with MM_PATH=3;
+ * even hop, no pre-emphasis) */
 int mm_plan_kernel_path(const mm_plan* plan);
 /* force the generic kernels (debug / cross-check); returns previous value */
 int mm_plan_force_generic(mm_plan* plan, int on);

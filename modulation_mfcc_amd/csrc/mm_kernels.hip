@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_fft16.hip.inc"
 #include "mm_logmel16w.hip.inc"
 #include "mm_change.hip.inc"
-#include "mm_fft2048.hip.inc"
+#include "mm_wpf.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 // plan
@@ -296,8 +296,9 @@ struct mm_plan {
   int* d_w16_part;
   int w16_n_runs, w16_n_tab16, w16_ok;
   size_t w16_lds_bytes;
-  float *d_k2_lane_tab, *d_k2_mel_lane;   // n_fft = 2048 wave-per-frame kernel
-  int k2_ok;
+  float *d_k2_lane_tab, *d_k2_mel_lane;   // wave-per-frame-group kernel (n_fft 512 / 1024 / 2048)
+  int k2_ok, wpf_r, wpf_waves;
+  size_t wpf_lds_bytes;
   int num_cus;
   // timing
   int timing_on;
@@ -570,21 +571,23 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         p->w16_ok = 1;
     }
   }
-  // n_fft = 2048 wave-per-frame kernel: even hop, no pre-emphasis, n_mels <= 256, and the mel
+  // wave-per-frame-group kernel (n_fft = 512*R, R = 1, 2, 4): even hop, no pre-emphasis, and the mel
   // sweep must advance by at most one filter between consecutive bins of a lane's 16-bin slice
-  if (cfg->n_fft == 2048 && (cfg->hop_length % 2) == 0 && cfg->preemph == 0.0f && cfg->n_mels <= MM_K2_MAXMEL) {
+  if ((cfg->n_fft == 512 || cfg->n_fft == 1024 || cfg->n_fft == 2048) && (cfg->hop_length % 2) == 0 &&
+      cfg->preemph == 0.0f && cfg->n_mels <= MM_WPF_MAXMEL) {
+    const int R = cfg->n_fft / 512, L = 16 * R, NC = 256 * R;
     mm::MelSweep sw2;
     if (mm::build_mel_sweep(*cfg, mel.data(), 1, &sw2)) {
-      std::vector<float> ml(64 * 36, 0.0f);
+      std::vector<float> ml((size_t)L * 36, 0.0f);
       bool ok = true;
-      for (int l = 0; l < 64 && ok; ++l) {
+      for (int l = 0; l < L && ok; ++l) {
         float* r = ml.data() + l * 36;
         int dprev = sw2.d[16 * l];
-        int dstart = dprev;
+        const int dstart = dprev;
         unsigned bits = 0;
-        const int nslots = (l == 63) ? 17 : 16;
+        const int nslots = (l == L - 1) ? 17 : 16;
         for (int i = 0; i < nslots; ++i) {
-          const int k = (i < 16) ? 16 * l + i : 1024;
+          const int k = (i < 16) ? 16 * l + i : NC;
           const int adv = sw2.d[k] - dprev;
           if (adv < 0 || adv > 1) { ok = false; break; }
           if (adv == 1) bits |= (1u << i);
@@ -595,30 +598,41 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         std::memcpy(&r[34], &dstart, 4);
         std::memcpy(&r[35], &bits, 4);
       }
-      std::vector<float> lt(64 * MM_K2_LT_PITCH, 0.0f);
-      for (int l = 0; l < 64; ++l) {
-        float* r = lt.data() + l * MM_K2_LT_PITCH;
-        const int pq = l & 3;
-        for (int n1 = 0; n1 < 16; ++n1) { r[2 * n1] = win[128 * n1 + 2 * l]; r[2 * n1 + 1] = win[128 * n1 + 2 * l + 1]; }
+      std::vector<float> lt((size_t)L * MM_WPF_LT_PITCH, 0.0f);
+      for (int l = 0; l < L; ++l) {
+        float* r = lt.data() + l * MM_WPF_LT_PITCH;
+        const int pq = l % R;
+        for (int n1 = 0; n1 < 16; ++n1) { r[2 * n1] = win[2 * L * n1 + 2 * l]; r[2 * n1 + 1] = win[2 * L * n1 + 2 * l + 1]; }
         for (int k1 = 1; k1 < 16; ++k1) {
-          const int i1 = ((l * k1) % 1024) * (MM_TW_N / 1024);   // W_1024^(n2*k1), n2 = lane
+          const int i1 = ((l * k1) % NC) * (MM_TW_N / NC);          // W_NC^(n2*k1), n2 = lane in frame
           r[32 + 2 * (k1 - 1)] = tw[2 * i1]; r[32 + 2 * (k1 - 1) + 1] = tw[2 * i1 + 1];
-          const int i2 = ((pq * k1) % 64) * (MM_TW_N / 64);       // W_64^(p*j)
+          const int i2 = ((pq * k1) % L) * (MM_TW_N / L);            // W_L^(p*j)
           r[64 + 2 * (k1 - 1)] = tw[2 * i2]; r[64 + 2 * (k1 - 1) + 1] = tw[2 * i2 + 1];
         }
         for (int i = 0; i < 8; ++i) {
-          const int idx = (l + 64 * i) * (MM_TW_N / 2048);        // 0.5 * (-i) * W_2048^k
+          const int idx = (l + L * i) * (MM_TW_N / (2 * NC));        // 0.5 * (-i) * W_n^k
           r[96 + 2 * i] = 0.5f * tw[2 * idx + 1]; r[96 + 2 * i + 1] = -0.5f * tw[2 * idx];
         }
       }
-      if (ok && upload(&p->d_k2_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
+      const int macc_stride = (cfg->n_mels + 63) / 64 * 64;
+      const int F = 4 / R;
+      const int xbuf = (R == 1) ? 1280 : 1152;
+      const int pbuf = F * (NC + NC / 16 + 4);
+      const size_t wave_bytes = (size_t)(xbuf + pbuf + F * macc_stride) * 4;
+      p->wpf_r = R;
+      p->wpf_waves = 12;
+      while (p->wpf_waves > 4 && (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes > MM_LM_LDS_MAX) p->wpf_waves -= 4;
+      p->wpf_lds_bytes = (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes;
+      const void* kfn[6] = {(const void*)logmel_wpf_kernel<1, 0>, (const void*)logmel_wpf_kernel<1, 1>,
+                            (const void*)logmel_wpf_kernel<2, 0>, (const void*)logmel_wpf_kernel<2, 1>,
+                            (const void*)logmel_wpf_kernel<4, 0>, (const void*)logmel_wpf_kernel<4, 1>};
+      bool attr_ok = p->wpf_lds_bytes <= MM_LM_LDS_MAX;
+      for (int i = 0; i < 6 && attr_ok; ++i)
+        attr_ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->wpf_lds_bytes) == hipSuccess;
+      if (ok && attr_ok && upload(&p->d_k2_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
           upload(&p->d_k2_mel_lane, ml.data(), ml.size() * 4) == MM_OK &&
-          hipFuncSetAttribute((const void*)logmel2048_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              MM_K2_LDS_BYTES) == hipSuccess &&
-          hipFuncSetAttribute((const void*)logmel2048_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              MM_K2_LDS_BYTES) == hipSuccess &&
           hipFuncSetAttribute((const void*)dct_clamp_fm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              64 * (MM_K2_MAXMEL + 1) * 4) == hipSuccess)
+                              64 * (MM_WPF_MAXMEL + 1) * 4) == hipSuccess)
         p->k2_ok = 1;
     }
   }
@@ -648,7 +662,8 @@ int mm_plan_config(const mm_plan* p, mm_config* out) {
 int mm_plan_kernel_path(const mm_plan* p) {
   if (!p) return MM_ERR_INVALID_ARG;
   if (p->force_generic) return 0;
-  if (p->k2_ok) return 3;
+  const bool force_wpf = getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 3;
+  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1)) return 3;
   return (p->path == 1 && p->w16_ok) ? 2 : p->path;
 }
 
@@ -671,23 +686,31 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
                        int64_t stride, float* out_power, float* out_logmel, int* clip_key,
                        hipStream_t st, bool frame_major = false, bool* is_fm = nullptr) {
   if (is_fm) *is_fm = false;
-  if (p->k2_ok && !p->force_generic && (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2) {
-    Logmel2048Params q;
+  const bool force_wpf = getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 3;
+  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1) && !p->force_generic &&
+      (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2) {
+    WpfParams q;
+    const int R = p->wpf_r, F = 4 / R;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
     q.n_frames = mm_num_frames(&p->cfg, n_samples);
-    q.total_frames = batch * q.n_frames;
+    q.groups_per_clip = (q.n_frames + F - 1) / F;
+    q.total_groups = batch * q.groups_per_clip;
     q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
+    q.macc_stride = (p->cfg.n_mels + 63) / 64 * 64; q.waves_per_wg = p->wpf_waves;
     q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane;
     q.out_logmel = out_logmel; q.clip_key = clip_key; q.out_power = out_power;
     if (frame_major) { q.sB = q.n_frames * q.n_mels; q.sT = q.n_mels; q.sM = 1; }
     else { q.sB = q.n_frames * q.n_mels; q.sT = 1; q.sM = q.n_frames; }
     if (is_fm) *is_fm = frame_major;
-    int64_t grid = (q.total_frames + MM_K2_WAVES - 1) / MM_K2_WAVES;
+    int64_t grid = (q.total_groups + p->wpf_waves - 1) / p->wpf_waves;
     if (grid > p->num_cus) grid = p->num_cus;
-    if (mode == 0)
-      hipLaunchKernelGGL(logmel2048_kernel<0>, dim3((unsigned)grid), dim3(64 * MM_K2_WAVES), MM_K2_LDS_BYTES, st, q);
-    else
-      hipLaunchKernelGGL(logmel2048_kernel<1>, dim3((unsigned)grid), dim3(64 * MM_K2_WAVES), MM_K2_LDS_BYTES, st, q);
+    const dim3 blk(64 * p->wpf_waves);
+    const size_t lds = p->wpf_lds_bytes;
+#define MM_WPF_LAUNCH(RR, MM) hipLaunchKernelGGL((logmel_wpf_kernel<RR, MM>), dim3((unsigned)grid), blk, lds, st, q)
+    if (R == 1) { if (mode == 0) MM_WPF_LAUNCH(1, 0); else MM_WPF_LAUNCH(1, 1); }
+    else if (R == 2) { if (mode == 0) MM_WPF_LAUNCH(2, 0); else MM_WPF_LAUNCH(2, 1); }
+    else { if (mode == 0) MM_WPF_LAUNCH(4, 0); else MM_WPF_LAUNCH(4, 1); }
+#undef MM_WPF_LAUNCH
     HIP_TRY(hipGetLastError());
     return MM_OK;
   }

@@ -42,6 +42,8 @@ class _variant:
         self.old = os.environ.get("MM_PATH")
         if self.which == "w8":
             os.environ["MM_PATH"] = "1"
+        if self.which == "wpf":
+            os.environ["MM_PATH"] = "3"
         self.plan.force_generic(self.which == "generic")
         return self
 
@@ -54,7 +56,7 @@ class _variant:
             os.environ["MM_PATH"] = self.old
 
 
-VARIANTS = ["w16", "w8", "generic"]
+VARIANTS = ["w16", "w8", "wpf", "generic"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -72,7 +74,8 @@ def test_kernel_variants_selected(gpu):
     assert _plan(kw).kernel_path == "radix16-w16"
     assert _plan(load_golden("refdefault_am")[0]).kernel_path == "radix16-w16"
     assert _plan({**kw, "n_mels": 256}).kernel_path == "radix16-w8"      # mel table too big for w16
-    assert _plan(load_golden("c4_am")[0]).kernel_path == "radix16-2048"    # n_fft 2048: wave-per-frame kernel
+    assert _plan(load_golden("c4_am")[0]).kernel_path == "radix16-wpf"     # n_fft 2048: wave-per-frame kernel
+    assert _plan(load_golden("odd_22k")[0]).kernel_path == "radix16-wpf"   # n_fft 1024, even hop
     assert _plan(load_golden("ragged_preemph")[0]).kernel_path == "generic"  # odd hop + pre-emphasis
 
 
@@ -101,7 +104,7 @@ def test_nfft2048_kernel_vs_generic_and_oracle(n, gpu):
     kw, _, _ = load_golden("c4_am")
     y = O.synth_clip(2000 + n, n, kw["sr"], "am" if n > 5000 else "noise")
     plan = _plan(kw)
-    assert plan.kernel_path == "radix16-2048"
+    assert plan.kernel_path == "radix16-wpf"
     d = _dev(np.stack([y, y[::-1].copy()]), gpu)
     want = [O.mfcc(c, O.OracleConfig(**kw)) for c in (y, y[::-1])]
     fast = plan.mfcc(d).cpu().numpy()
