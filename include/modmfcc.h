@@ -155,6 +155,14 @@ int mm_mfcc_change_f64(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_
                        void* d_workspace, size_t ws_bytes, void* stream);
 size_t mm_change_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_frames);
 
+/* Framewise RMS (row N3): librosa.feature.rms(y, frame_length, hop_length, center, pad_mode=
+ * 'constant') as called at script/calc.py:331 / script/mfcc.py:247.  d_audio [batch][audio_stride]
+ * -> d_rms [batch][n_out], n_out = 1 + (n_samples + 2*(center ? frame_length/2 : 0) - frame_length)
+ * / hop_length.  Needs no plan. */
+int64_t mm_rms_num_frames(int64_t n_samples, int32_t frame_length, int32_t hop_length, int32_t center);
+int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t audio_stride,
+               int32_t frame_length, int32_t hop_length, int32_t center, float* d_rms, void* stream);
+
 /* ---- per-kernel device timing (hipEvents on the launch stream) ------------------------- */
 int mm_timing_enable(mm_plan* plan, int on);
 /* synchronises the recorded events; ms_sum[s]/count[s] = average launch duration of stage s;

@@ -952,6 +952,48 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   return MM_OK;
 }
 
+// one wave per output frame: coalesced strided sum of squares, zero padding outside the clip
+__global__ __launch_bounds__(256) void rms_frames_kernel(const float* __restrict__ audio, int64_t n_samples,
+                                                         int64_t stride, int frame_length, int hop, int pad,
+                                                         int64_t n_out, int64_t total, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= total) return;
+  const int64_t b = w / n_out, t = w - b * n_out;
+  const float* a = audio + b * stride;
+  const int64_t start = t * hop - pad;
+  float acc = 0.0f;
+  for (int j = lane; j < frame_length; j += 64) {
+    const int64_t i = start + j;
+    const float v = (i >= 0 && i < n_samples) ? a[i] : 0.0f;
+    acc = fmaf(v, v, acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) out[w] = sqrtf(acc / (float)frame_length);
+}
+
+int64_t mm_rms_num_frames(int64_t n_samples, int32_t frame_length, int32_t hop_length, int32_t center) {
+  if (n_samples < 1 || frame_length < 1 || hop_length < 1) return MM_ERR_INVALID_ARG;
+  const int64_t padded = n_samples + (center ? 2 * (int64_t)(frame_length / 2) : 0);
+  if (padded < frame_length) return MM_ERR_INVALID_ARG;
+  return 1 + (padded - frame_length) / hop_length;
+}
+
+int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t stride, int32_t frame_length,
+               int32_t hop_length, int32_t center, float* d_rms, void* stream) {
+  if (!d_audio || !d_rms || batch < 1 || stride < n_samples) return MM_ERR_INVALID_ARG;
+  const int64_t n_out = mm_rms_num_frames(n_samples, frame_length, hop_length, center);
+  if (n_out < 0) return (int)n_out;
+  const int64_t total = batch * n_out;
+  const int64_t grid = (total + 3) / 4;
+  if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(rms_frames_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_audio,
+                     n_samples, stride, frame_length, hop_length, center ? frame_length / 2 : 0, n_out, total, d_rms);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
 int mm_timing_enable(mm_plan* p, int on) {
   if (!p) return MM_ERR_INVALID_ARG;
   p->timing_on = on ? 1 : 0;

@@ -356,3 +356,17 @@ def test_random_configs_match_oracle(idx, gpu):
             want = O.mfcc(clips[i], O.OracleConfig(**okw))
             assert got[i].shape == want.shape
             mfcc_close(got[i], want, f"cfg {idx} ({plan.kernel_path}) {kw} clip {i}")
+
+
+@pytest.mark.parametrize("n,fl,hop,center", [(4000, 400, 80, True), (4000, 401, 77, True), (1600, 1600, 160, False),
+                                              (50, 400, 80, True), (16000, 1600, 160, True)])
+def test_rms_frames_on_device(n, fl, hop, center, gpu):
+    """Row N3: mm_rms_f32 == librosa.feature.rms(center, pad_mode='constant') (script/calc.py:331)."""
+    from modulation_mfcc_amd import rms_batch
+    rng = np.random.default_rng(n + fl)
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    got = rms_batch(_dev(x, gpu), fl, hop, center).cpu().numpy()
+    for i in range(3):
+        want = O.rms_envelope(x[i], fl, hop, center)
+        assert got[i].shape == want.shape
+        np.testing.assert_allclose(got[i], want, rtol=2e-6, atol=1e-7)
