@@ -121,6 +121,12 @@ def main():
     ap.add_argument("--generic", action="store_true", help="force the generic kernels")
     a = ap.parse_args()
 
+    # Anything libraries print on stdout (RCCL prints a version banner there at communicator init)
+    # goes to stderr: stdout carries exactly ONE line, the JSON result.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from modulation_mfcc_amd import MfccConfig, MfccPlan
@@ -135,9 +141,14 @@ def main():
         raise SystemExit("launch N>1 with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # MM_BENCH_FORCE_DIST=1: take the N>1 code path (process group, pipelined gather) even with a
+    # single rank -- a rehearsal of that path on a 1-GPU box
+    use_dist = world > 1 or bool(os.environ.get("MM_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     B, secs, kw, with_mod = WORKLOADS[a.workload]
     if a.clips:
@@ -155,8 +166,8 @@ def main():
     # kernels of step k+1 (every step's gather still completes inside the timed region)
     lay = SlabLayout.make(cfg, B, n, with_mod)
     n_mod = lay.n_mod
-    pg = PipelinedGather(lay.numel, dev) if world > 1 else None
-    slab1 = torch.empty(lay.numel, dtype=torch.float32, device=dev) if world == 1 else None
+    pg = PipelinedGather(lay.numel, dev) if use_dist else None
+    slab1 = torch.empty(lay.numel, dtype=torch.float32, device=dev) if not use_dist else None
     plan.workspace(B, n)
 
     def step():
@@ -176,7 +187,7 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     plan.timing_enable(True)
     torch.cuda.synchronize()
@@ -185,12 +196,12 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     plan.timing_enable(False)
     stage = plan.timing_read()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -252,9 +263,16 @@ def main():
         if world == 1 and not a.no_cpu:
             ns = min(B, 64)
             res["cpu_baseline"] = cpu_baseline(audio[:ns].cpu().numpy(), kw, with_mod)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)
+        os.dup2(2, 1)
 
-    if world > 1:
+    if use_dist:
+        if pg is not None and rank == 0 and os.environ.get("MM_BENCH_FORCE_DIST"):
+            # rehearsal check: what arrived at the root is what the last steps produced
+            last = (pg.k - 1) % pg.depth
+            assert torch.equal(pg.received[last][0], pg.slabs[last]), "gathered slab differs"
         dist.barrier()
         dist.destroy_process_group()
 
