@@ -532,9 +532,10 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       return rc;
     }
     if (hipFuncSetAttribute((const void*)logmel512_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)p->lm_lds_bytes) == hipSuccess &&
+                            MM_LM_LDS_MAX) == hipSuccess &&
         hipFuncSetAttribute((const void*)logmel512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)p->lm_lds_bytes) == hipSuccess)
+                            MM_LM_LDS_MAX) == hipSuccess)   // the attribute is per function, not per plan:
+                                                             // always the 160 KB maximum
       p->path = 1;
     // 16-wave variant (4 waves per SIMD): needs its own 16-way mel partition and lane records
     mm::MelSweep sw16;
@@ -565,9 +566,9 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
           upload(&p->d_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
           upload(&p->d_w16_part, r16.part.data(), r16.part.size() * 4) == MM_OK &&
           hipFuncSetAttribute((const void*)logmel512w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)p->w16_lds_bytes) == hipSuccess &&
+                              MM_LM_LDS_MAX) == hipSuccess &&
           hipFuncSetAttribute((const void*)logmel512w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)p->w16_lds_bytes) == hipSuccess)
+                              MM_LM_LDS_MAX) == hipSuccess)
         p->w16_ok = 1;
     }
   }
@@ -628,7 +629,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
                             (const void*)logmel_wpf_kernel<4, 0>, (const void*)logmel_wpf_kernel<4, 1>};
       bool attr_ok = p->wpf_lds_bytes <= MM_LM_LDS_MAX;
       for (int i = 0; i < 6 && attr_ok; ++i)
-        attr_ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->wpf_lds_bytes) == hipSuccess;
+        attr_ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
       if (ok && attr_ok && upload(&p->d_k2_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
           upload(&p->d_k2_mel_lane, ml.data(), ml.size() * 4) == MM_OK &&
           hipFuncSetAttribute((const void*)dct_clamp_fm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

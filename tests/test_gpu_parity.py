@@ -370,3 +370,15 @@ def test_rms_frames_on_device(n, fl, hop, center, gpu):
         want = O.rms_envelope(x[i], fl, hop, center)
         assert got[i].shape == want.shape
         np.testing.assert_allclose(got[i], want, rtol=2e-6, atol=1e-7)
+
+
+def test_plans_with_different_lds_sizes_coexist(gpu):
+    """The dynamic-LDS limit is a per-function attribute: creating a plan with a small mel table after
+    one with a large table must not break launches of the first (n_mels 128 needs more LDS than 40)."""
+    from modulation_mfcc_amd import MfccConfig, MfccPlan
+    kw, y, exp = load_golden("c1_am")
+    big = MfccPlan(MfccConfig(**{**kw, "n_mels": 128, "fmin": 0.0}))
+    small = MfccPlan(MfccConfig(**kw))
+    d = _dev(y, gpu)[None, :]
+    mfcc_close(small.mfcc(d)[0].cpu().numpy(), exp["mfcc"], "small")
+    mfcc_close(big.mfcc(d)[0].cpu().numpy(), O.mfcc(y, O.OracleConfig(**{**kw, "n_mels": 128, "fmin": 0.0})), "big")
