@@ -63,7 +63,7 @@ typedef struct mm_config {
   float top_db;       /* 80; < 0 disables the per-clip clamp                                  */
   float amin;         /* 1e-10                                                                */
   int32_t center;     /* must be 1 (librosa center=True, pad_mode='constant')                 */
-  int32_t n_mod_fft;  /* trajectory rFFT length; 0 = next power of two >= n_frames            */
+  int32_t n_mod_fft;  /* trajectory rFFT length (<= 8192); 0 = next power of two >= n_frames  */
 } mm_config;
 
 typedef struct mm_plan mm_plan;
@@ -138,7 +138,8 @@ int mm_logmel_f32(mm_plan* plan, const float* d_audio, int64_t batch, int64_t n_
 int mm_stft_power_f32(mm_plan* plan, const float* d_audio, int64_t batch, int64_t n_samples,
                       int64_t audio_stride, float* d_power, void* stream);
 
-/* rows of `in_len` (<= n, zero padded) real samples -> complex64 [rows][n/2+1] interleaved.  */
+/* rows of `in_len` (<= n, zero padded) real samples -> complex64 [rows][n/2+1] interleaved;
+ * n a power of two in [32, 8192].                                                             */
 int mm_rfft_f32(mm_plan* plan, const float* d_in, int64_t rows, int64_t in_len,
                 int64_t in_stride, int32_t n, float* d_out, void* stream);
 

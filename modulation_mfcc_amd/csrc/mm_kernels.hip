@@ -401,7 +401,7 @@ int32_t mm_mod_fft_len(const mm_config* c, int64_t n_frames) {
   if (c->n_mod_fft) return c->n_mod_fft >= n_frames ? c->n_mod_fft : MM_ERR_INVALID_ARG;
   int64_t n = 32;
   while (n < n_frames) n *= 2;
-  return n <= 4096 ? (int32_t)n : MM_ERR_UNSUPPORTED;
+  return n <= 8192 ? (int32_t)n : MM_ERR_UNSUPPORTED;   // trajectory rFFT: up to 8192 frames per clip
 }
 
 int mm_build_window(const mm_config* c, float* out) {
@@ -864,6 +864,14 @@ static int launch_rfft(mm_plan* p, const float* d_in, int64_t rows, int64_t in_l
   const int nc = n / 2;
   const int64_t grid = (rows + 4 * q.rows_per_wave - 1) / (4 * q.rows_per_wave);
   if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  if ((size_t)4 * nc * 8 > 65536) {   // n = 8192 needs 128 KB of dynamic LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(hipFuncSetAttribute((const void*)rfft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  163840));
+      attr_set = true;
+    }
+  }
   hipLaunchKernelGGL(rfft_generic_kernel, dim3((unsigned)grid), dim3(256), (size_t)4 * nc * 8, st, q);
   HIP_TRY(hipGetLastError());
   return MM_OK;
@@ -872,7 +880,7 @@ static int launch_rfft(mm_plan* p, const float* d_in, int64_t rows, int64_t in_l
 int mm_rfft_f32(mm_plan* p, const float* d_in, int64_t rows, int64_t in_len, int64_t in_stride,
                 int32_t n, float* d_out, void* stream) {
   if (!p || !d_in || !d_out || rows < 1 || in_len < 1 || in_stride < in_len) return MM_ERR_INVALID_ARG;
-  if (n < 32 || n > 4096 || (n & (n - 1))) return MM_ERR_UNSUPPORTED;
+  if (n < 32 || n > 8192 || (n & (n - 1))) return MM_ERR_UNSUPPORTED;
   if (in_len > n) return MM_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   StageTimer tm(p, MM_STAGE_RFFT, st);

@@ -51,6 +51,7 @@ def test_config_struct_layout_and_defaults():
     (dict(win_length=600), ValueError), (dict(hop_length=0), ValueError),
     (dict(n_mfcc=200), ValueError), (dict(fmax=50.0), ValueError), (dict(center=False), NotImplementedError),
     (dict(amin=0.0), ValueError), (dict(n_mod_fft=1000), NotImplementedError),
+    (dict(n_mod_fft=16384), NotImplementedError),
 ])
 def test_validate_rejects(bad, exc):
     with pytest.raises(exc):

@@ -175,7 +175,8 @@ def test_batch_rows_are_independent_and_strided(gpu):
             np.testing.assert_array_equal(again[0], got[3])   # bit-identical at any batch position
 
 
-@pytest.mark.parametrize("n,L", [(512, 512), (1024, 1001), (2048, 2048), (64, 40), (4096, 4096), (256, 1)])
+@pytest.mark.parametrize("n,L", [(512, 512), (1024, 1001), (2048, 2048), (64, 40), (4096, 4096), (256, 1),
+                                 (8192, 6001)])
 def test_rfft_rows(n, L, gpu):
     rng = np.random.default_rng(n + L)
     x = rng.standard_normal((37, L)).astype(np.float32)
