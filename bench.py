@@ -258,7 +258,23 @@ def main():
                              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": bpf,
                              "frames_per_s": rows / (ms / cnt * 1e-3), "avg_launch_ms": ms / cnt}
-        del frames_buf, spec
+        # practical HBM ceiling of this device: a plain device-to-device copy (bytes read + written)
+        src_c = frames_buf.view(-1)[: (1 << 28)]              # 1 GiB
+        dst_c = torch.empty_like(src_c)
+        for _ in range(2):
+            dst_c.copy_(src_c)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst_c.copy_(src_c)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src_c.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        res["rfft_stage"]["device_copy_GBs"] = copy_gbs
+        res["rfft_stage"]["frac_of_device_copy"] = ach / copy_gbs
+        if "roofline" in res:
+            res["roofline"]["device_copy_GBs"] = copy_gbs
+        del frames_buf, spec, src_c, dst_c
 
         if world == 1 and not a.no_cpu:
             ns = min(B, 64)
