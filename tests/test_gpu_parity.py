@@ -383,3 +383,35 @@ def test_plans_with_different_lds_sizes_coexist(gpu):
     d = _dev(y, gpu)[None, :]
     mfcc_close(small.mfcc(d)[0].cpu().numpy(), exp["mfcc"], "small")
     mfcc_close(big.mfcc(d)[0].cpu().numpy(), O.mfcc(y, O.OracleConfig(**{**kw, "n_mels": 128, "fmin": 0.0})), "big")
+
+
+def test_calls_are_graph_capturable(gpu):
+    """include/modmfcc.h promises: no allocation, no synchronisation inside compute calls -- so a
+    step (MFCC + modulation spectrum) can be captured into a hipGraph and replayed."""
+    import torch
+    kw, _, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    clips = np.stack([O.synth_clip(300 + i, 16000, 16000, "am") for i in range(8)])
+    audio = _dev(clips, gpu)
+    m_ref = plan.mfcc(audio)
+    ms_ref = plan.modspec(m_ref)
+    m = torch.empty_like(m_ref)
+    ms = torch.empty_like(ms_ref)
+    plan.workspace(8, 16000)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                       # warm-up on the side stream
+        plan.mfcc(audio, out=m)
+        plan.modspec(m, out=ms)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.mfcc(audio, out=m)
+        plan.modspec(m, out=ms)
+    m.zero_(); ms.zero_()
+    audio.copy_(_dev(clips[::-1].copy(), gpu))       # new input, same buffers
+    g.replay()
+    torch.cuda.synchronize()
+    want = plan.mfcc(_dev(clips[::-1].copy(), gpu))
+    assert torch.equal(m, want)
+    assert torch.equal(ms, plan.modspec(want))
