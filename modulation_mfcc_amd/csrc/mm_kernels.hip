@@ -297,6 +297,8 @@ struct mm_plan {
   int w16_n_runs, w16_n_tab16, w16_ok;
   size_t w16_lds_bytes;
   float *d_k2_lane_tab, *d_k2_mel_lane;   // wave-per-frame-group kernel (n_fft 512 / 1024 / 2048)
+  float* d_rf2k_lane_tab;                 // rfft_wpf_kernel<4> (stage-isolated rFFT, n = 2048)
+  int rf2k_ok;
   int k2_ok, wpf_r, wpf_waves;
   size_t wpf_lds_bytes;
   int num_cus;
@@ -457,6 +459,30 @@ int mm_build_mel_runs(const mm_config* c, int n_waves, int32_t* hdr, int32_t hdr
 }
 int mm_build_butter_sos(int order, double wn, double* sos) { return mm::build_butter_sos(order, wn, sos); }
 
+// Per-lane constants of the wpf transform (mm_wpf.hip.inc) for n = 512*R: window (or zeros when
+// win == nullptr: the plain rFFT kernel does not read it) | W_NC^(l*k1) | W_L^(p*j) | split twiddles.
+static std::vector<float> wpf_lane_table(int R, const float* win, const float* tw) {
+  const int L = 16 * R, NC = 256 * R;
+  std::vector<float> lt((size_t)L * MM_WPF_LT_PITCH, 0.0f);
+  for (int l = 0; l < L; ++l) {
+    float* r = lt.data() + l * MM_WPF_LT_PITCH;
+    const int pq = l % R;
+    if (win)
+      for (int n1 = 0; n1 < 16; ++n1) { r[2 * n1] = win[2 * L * n1 + 2 * l]; r[2 * n1 + 1] = win[2 * L * n1 + 2 * l + 1]; }
+    for (int k1 = 1; k1 < 16; ++k1) {
+      const int i1 = ((l * k1) % NC) * (MM_TW_N / NC);          // W_NC^(n2*k1), n2 = lane in frame
+      r[32 + 2 * (k1 - 1)] = tw[2 * i1]; r[32 + 2 * (k1 - 1) + 1] = tw[2 * i1 + 1];
+      const int i2 = ((pq * k1) % L) * (MM_TW_N / L);            // W_L^(p*j)
+      r[64 + 2 * (k1 - 1)] = tw[2 * i2]; r[64 + 2 * (k1 - 1) + 1] = tw[2 * i2 + 1];
+    }
+    for (int i = 0; i < 8; ++i) {
+      const int idx = (l + L * i) * (MM_TW_N / (2 * NC));        // 0.5 * (-i) * W_n^k
+      r[96 + 2 * i] = 0.5f * tw[2 * idx + 1]; r[96 + 2 * i + 1] = -0.5f * tw[2 * idx];
+    }
+  }
+  return lt;
+}
+
 int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   if (!out) return MM_ERR_INVALID_ARG;
   *out = nullptr;
@@ -480,6 +506,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_sw_tab = nullptr; p->d_sw_part = nullptr;
   p->d_w16_tab = p->d_lane_tab = nullptr; p->d_w16_part = nullptr; p->w16_ok = 0;
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0;
+  p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
     g_hip_err = "hipGetDevice failed (no GPU?)";
@@ -599,22 +626,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         std::memcpy(&r[34], &dstart, 4);
         std::memcpy(&r[35], &bits, 4);
       }
-      std::vector<float> lt((size_t)L * MM_WPF_LT_PITCH, 0.0f);
-      for (int l = 0; l < L; ++l) {
-        float* r = lt.data() + l * MM_WPF_LT_PITCH;
-        const int pq = l % R;
-        for (int n1 = 0; n1 < 16; ++n1) { r[2 * n1] = win[2 * L * n1 + 2 * l]; r[2 * n1 + 1] = win[2 * L * n1 + 2 * l + 1]; }
-        for (int k1 = 1; k1 < 16; ++k1) {
-          const int i1 = ((l * k1) % NC) * (MM_TW_N / NC);          // W_NC^(n2*k1), n2 = lane in frame
-          r[32 + 2 * (k1 - 1)] = tw[2 * i1]; r[32 + 2 * (k1 - 1) + 1] = tw[2 * i1 + 1];
-          const int i2 = ((pq * k1) % L) * (MM_TW_N / L);            // W_L^(p*j)
-          r[64 + 2 * (k1 - 1)] = tw[2 * i2]; r[64 + 2 * (k1 - 1) + 1] = tw[2 * i2 + 1];
-        }
-        for (int i = 0; i < 8; ++i) {
-          const int idx = (l + L * i) * (MM_TW_N / (2 * NC));        // 0.5 * (-i) * W_n^k
-          r[96 + 2 * i] = 0.5f * tw[2 * idx + 1]; r[96 + 2 * i + 1] = -0.5f * tw[2 * idx];
-        }
-      }
+      std::vector<float> lt = wpf_lane_table(R, win.data(), tw.data());
       const int macc_stride = (cfg->n_mels + 63) / 64 * 64;
       const int F = 4 / R;
       const int xbuf = (R == 1) ? 1280 : 1152;
@@ -637,6 +649,15 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         p->k2_ok = 1;
     }
   }
+  {
+    const std::vector<float> lt = wpf_lane_table(4, nullptr, tw.data());
+    if (upload(&p->d_rf2k_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
+        hipFuncSetAttribute((const void*)rfft_wpf_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            MM_LM_LDS_MAX) == hipSuccess &&
+        hipFuncSetAttribute((const void*)rfft_wpf_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            MM_LM_LDS_MAX) == hipSuccess)
+      p->rf2k_ok = 1;
+  }
   *out = p;
   return MM_OK;
 }
@@ -649,6 +670,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_sw_tab); (void)hipFree(p->d_sw_part);
   (void)hipFree(p->d_w16_tab); (void)hipFree(p->d_lane_tab); (void)hipFree(p->d_w16_part);
   (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane);
+  (void)hipFree(p->d_rf2k_lane_tab);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
   return MM_OK;
@@ -858,6 +880,17 @@ static int launch_rfft(mm_plan* p, const float* d_in, int64_t rows, int64_t in_l
       if (fast) hipLaunchKernelGGL((rfft16_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, st, q);
       else hipLaunchKernelGGL((rfft16_kernel<2, false>), dim3((unsigned)grid), dim3(256), 0, st, q);
     }
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
+  if (!p->force_generic && n == 2048 && p->rf2k_ok) {
+    // one row per wave, 8 waves per workgroup, two workgroups per CU
+    int64_t grid = (rows + 7) / 8;
+    if (grid > 512) grid = 512;
+    const size_t lds = (size_t)(64 * MM_WPF_LT_PITCH + 8 * WpfGeo<4>::XBUF) * 4;
+    const bool fast = (in_len == n) && (in_stride % 2 == 0) && (((uintptr_t)d_in & 7) == 0);
+    if (fast) hipLaunchKernelGGL((rfft_wpf_kernel<4, true>), dim3((unsigned)grid), dim3(512), lds, st, q, p->d_rf2k_lane_tab);
+    else hipLaunchKernelGGL((rfft_wpf_kernel<4, false>), dim3((unsigned)grid), dim3(512), lds, st, q, p->d_rf2k_lane_tab);
     HIP_TRY(hipGetLastError());
     return MM_OK;
   }

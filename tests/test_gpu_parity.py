@@ -175,8 +175,8 @@ def test_batch_rows_are_independent_and_strided(gpu):
             np.testing.assert_array_equal(again[0], got[3])   # bit-identical at any batch position
 
 
-@pytest.mark.parametrize("n,L", [(512, 512), (1024, 1001), (2048, 2048), (64, 40), (4096, 4096), (256, 1),
-                                 (8192, 6001)])
+@pytest.mark.parametrize("n,L", [(512, 512), (1024, 1001), (2048, 2048), (2048, 1500), (2048, 1), (64, 40),
+                                 (4096, 4096), (256, 1), (8192, 6001)])
 def test_rfft_rows(n, L, gpu):
     rng = np.random.default_rng(n + L)
     x = rng.standard_normal((37, L)).astype(np.float32)
@@ -186,6 +186,32 @@ def test_rfft_rows(n, L, gpu):
     assert got.shape == want.shape == (37, n // 2 + 1)
     scale = np.abs(want).max()
     assert np.abs(got - want).max() <= 2e-6 * scale * np.log2(n)
+
+
+def test_rfft_2048_many_rows(gpu):
+    """n = 2048 runs on the wave-per-row kernel: more rows than one pass of the persistent grid
+    (512 workgroups x 8 rows), aligned / odd-pitch / offset views, and the generic kernel beside it."""
+    import torch
+    rng = np.random.default_rng(2048)
+    rows = 4096 + 777
+    x = rng.standard_normal((rows, 2048)).astype(np.float32)
+    want = O.rfft_rows(x, 2048)
+    tol = 2e-6 * np.abs(want).max() * 11
+    kw, _, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    xd = _dev(x, gpu)
+    got = plan.rfft(xd, 2048).cpu().numpy()
+    assert np.abs(got - want).max() <= tol
+    big = torch.zeros((rows, 2048 + 3), dtype=torch.float32, device=gpu)
+    big[:, 1:2049] = xd
+    got_odd = plan.rfft(big[:, 1:2049], 2048).cpu().numpy()      # odd pitch, 4-byte aligned rows
+    assert np.abs(got_odd - want).max() <= tol
+    plan.force_generic(True)
+    try:
+        got_gen = plan.rfft(xd, 2048).cpu().numpy()
+    finally:
+        plan.force_generic(False)
+    assert np.abs(got_gen - want).max() <= tol
 
 
 def test_modspec_matches_oracle(gpu):
