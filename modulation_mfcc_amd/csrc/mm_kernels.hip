@@ -459,6 +459,17 @@ int mm_build_mel_runs(const mm_config* c, int n_waves, int32_t* hdr, int32_t hdr
 }
 int mm_build_butter_sos(int order, double wn, double* sos) { return mm::build_butter_sos(order, wn, sos); }
 
+// mm_build_mel_runs emits a 4-bin group as {wlo x4, whi x4}; the kernels want {wlo0, whi0, wlo1, whi1}
+// {wlo2, whi2, wlo3, whi3}: (wlo_i, whi_i) is then an aligned register pair and the two accumulators
+// advance with one v_pk_fma_f32 per bin, no register shuffling.
+static void interleave_run_groups(float* grp, size_t n_groups) {
+  for (size_t g = 0; g < n_groups; ++g) {
+    float* r = grp + 8 * g;
+    const float t[8] = {r[0], r[4], r[1], r[5], r[2], r[6], r[3], r[7]};
+    std::memcpy(r, t, sizeof t);
+  }
+}
+
 // Per-lane constants of the wpf transform (mm_wpf.hip.inc) for n = 512*R: window (or zeros when
 // win == nullptr: the plain rFFT kernel does not read it) | W_NC^(l*k1) | W_L^(p*j) | split twiddles.
 static std::vector<float> wpf_lane_table(int R, const float* win, const float* tw) {
@@ -549,6 +560,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     std::vector<float> tab(runs.hdr.size() + runs.grp.size());
     std::memcpy(tab.data(), runs.hdr.data(), runs.hdr.size() * 4);
     std::memcpy(tab.data() + runs.hdr.size(), runs.grp.data(), runs.grp.size() * 4);
+    interleave_run_groups(tab.data() + runs.hdr.size(), runs.grp.size() / 8);
     p->sw_n_runs = (int)(runs.hdr.size() / 4);
     p->sw_n_tab16 = (int)(tab.size() / 4);
     p->lm_lds_bytes = (size_t)MM_LM_TAB_OFF + tab.size() * 4;
@@ -572,6 +584,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       std::vector<float> tab16(r16.hdr.size() + r16.grp.size());
       std::memcpy(tab16.data(), r16.hdr.data(), r16.hdr.size() * 4);
       std::memcpy(tab16.data() + r16.hdr.size(), r16.grp.data(), r16.grp.size() * 4);
+      interleave_run_groups(tab16.data() + r16.hdr.size(), r16.grp.size() / 8);
       p->w16_n_runs = (int)(r16.hdr.size() / 4);
       p->w16_n_tab16 = (int)(tab16.size() / 4);
       p->w16_lds_bytes = (size_t)MM_W16_TAB_OFF + tab16.size() * 4;
