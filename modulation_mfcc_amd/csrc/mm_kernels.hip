@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_fft16.hip.inc"
 #include "mm_logmel16w.hip.inc"
 #include "mm_change.hip.inc"
+#include "mm_logmel16s.hip.inc"
 #include "mm_wpf.hip.inc"
 
 // ------------------------------------------------------------------------------------------
@@ -296,6 +297,8 @@ struct mm_plan {
   int* d_w16_part;
   int w16_n_runs, w16_n_tab16, w16_ok;
   size_t w16_lds_bytes;
+  int s16_nr;                      // staged-sample variant: 16-byte groups per thread and tile (0: not usable)
+  size_t s16_lds_bytes;
   float *d_k2_lane_tab, *d_k2_mel_lane;   // wave-per-frame-group kernel (n_fft 512 / 1024 / 2048)
   float* d_rf2k_lane_tab;                 // rfft_wpf_kernel<4> (stage-isolated rFFT, n = 2048)
   int rf2k_ok;
@@ -515,7 +518,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_window = nullptr; p->d_tw = nullptr; p->d_mel_start = p->d_mel_len = p->d_mel_off = nullptr;
   p->d_mel_w = nullptr; p->d_dct_t = nullptr;
   p->d_sw_tab = nullptr; p->d_sw_part = nullptr;
-  p->d_w16_tab = p->d_lane_tab = nullptr; p->d_w16_part = nullptr; p->w16_ok = 0;
+  p->d_w16_tab = p->d_lane_tab = nullptr; p->d_w16_part = nullptr; p->w16_ok = 0; p->s16_nr = 0; p->s16_lds_bytes = 0;
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->num_cus = 256;
@@ -610,6 +613,19 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
           hipFuncSetAttribute((const void*)logmel512w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               MM_LM_LDS_MAX) == hipSuccess)
         p->w16_ok = 1;
+      // staged-sample variant (mm_logmel16s.hip.inc): the tile's 63*hop + 512 samples must fit NR*4096 floats
+      p->s16_nr = 0;
+      if (p->w16_ok) {
+        const int span = 63 * cfg->hop_length + 512;
+        const int nr = span <= 3 * 4096 ? 3 : (span <= 4 * 4096 ? 4 : 0);
+        const size_t lds = nr ? (size_t)(nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tab16.size() * 4 : 0;
+        const void* kfn[4] = {(const void*)logmel512s_kernel<0, 3>, (const void*)logmel512s_kernel<1, 3>,
+                              (const void*)logmel512s_kernel<0, 4>, (const void*)logmel512s_kernel<1, 4>};
+        bool ok = nr && lds <= MM_LM_LDS_MAX;
+        for (int i = 0; i < 4 && ok; ++i)
+          ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
+        if (ok) { p->s16_nr = nr; p->s16_lds_bytes = lds; }
+      }
     }
   }
   // wave-per-frame-group kernel (n_fft = 512*R, R = 1, 2, 4): even hop, no pre-emphasis, and the mel
@@ -675,6 +691,12 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   return MM_OK;
 }
 
+#ifdef MM_STAMP
+extern "C" int mm_debug_stamps(unsigned int* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm_stamp_acc), sizeof(unsigned int) * 256) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int mm_plan_destroy(mm_plan* p) {
   if (!p) return MM_OK;
   (void)hipFree(p->d_window); (void)hipFree(p->d_tw); (void)hipFree(p->d_mel_start);
@@ -700,7 +722,12 @@ int mm_plan_kernel_path(const mm_plan* p) {
   if (p->force_generic) return 0;
   const bool force_wpf = getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 3;
   if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1)) return 3;
-  return (p->path == 1 && p->w16_ok) ? 2 : p->path;
+  if (p->path == 1 && p->w16_ok) {
+    const int mp = getenv("MM_PATH") ? atoi(getenv("MM_PATH")) : 0;
+    if (mp == 1) return 1;
+    return (p->s16_nr && mp != 2) ? 4 : 2;
+  }
+  return p->path;
 }
 
 int mm_plan_force_generic(mm_plan* p, int on) {
@@ -768,6 +795,19 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     if (use_w16) {
       q.mel_tab = (const float4*)p->d_w16_tab; q.n_runs = p->w16_n_runs; q.n_tab16 = p->w16_n_tab16;
       q.wave_part = p->d_w16_part;
+      const bool staged = p->s16_nr && (stride % 4) == 0 && (n_samples % 4) == 0 && n_samples >= 4 &&
+                          (((uintptr_t)d_audio) & 15) == 0 && !(getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 2);
+      if (staged) {
+        if (p->s16_nr == 3) {
+          if (mode == 0) hipLaunchKernelGGL((logmel512s_kernel<0, 3>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
+          else hipLaunchKernelGGL((logmel512s_kernel<1, 3>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
+        } else {
+          if (mode == 0) hipLaunchKernelGGL((logmel512s_kernel<0, 4>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
+          else hipLaunchKernelGGL((logmel512s_kernel<1, 4>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
+        }
+        HIP_TRY(hipGetLastError());
+        return MM_OK;
+      }
       if (mode == 0)
         hipLaunchKernelGGL(logmel512w_kernel<0>, dim3((unsigned)grid), dim3(1024), p->w16_lds_bytes, st, q);
       else

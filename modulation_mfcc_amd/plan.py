@@ -191,7 +191,7 @@ class MfccPlan:
 
     @property
     def kernel_path(self):
-        return {0: "generic", 1: "radix16-w8", 2: "radix16-w16", 3: "radix16-wpf"}[self._lib.mm_plan_kernel_path(self._h)]
+        return {0: "generic", 1: "radix16-w8", 2: "radix16-w16", 3: "radix16-wpf", 4: "radix16-w16s"}[self._lib.mm_plan_kernel_path(self._h)]
 
     def force_generic(self, on=True):
         return self._lib.mm_plan_force_generic(self._h, 1 if on else 0)

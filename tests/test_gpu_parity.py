@@ -30,9 +30,11 @@ def test_native_library_is_loaded(gpu):
 
 
 class _variant:
-    """Select the fused-kernel variant for the calls inside: 'w16' (default where it applies), 'w8'
-    (MM_PATH=1: the 8-wave kernel, otherwise only used when the mel table is too big for w16) or
-    'generic'.  Configurations a variant does not cover fall through to the next one."""
+    """Select the fused-kernel variant for the calls inside: 'w16s' (default where it applies: 16 waves,
+    samples staged through LDS), 'w16' (MM_PATH=2: 16 waves, direct loads -- otherwise used for unaligned
+    or odd-length input), 'w8' (MM_PATH=1: the 8-wave kernel, otherwise only used when the mel table is
+    too big for w16), 'wpf' (MM_PATH=3) or 'generic'.  Configurations a variant does not cover fall
+    through to the next one."""
 
     def __init__(self, plan, which):
         self.plan, self.which = plan, which
@@ -42,6 +44,8 @@ class _variant:
         self.old = os.environ.get("MM_PATH")
         if self.which == "w8":
             os.environ["MM_PATH"] = "1"
+        if self.which == "w16":
+            os.environ["MM_PATH"] = "2"
         if self.which == "wpf":
             os.environ["MM_PATH"] = "3"
         self.plan.force_generic(self.which == "generic")
@@ -56,7 +60,7 @@ class _variant:
             os.environ["MM_PATH"] = self.old
 
 
-VARIANTS = ["w16", "w8", "wpf", "generic"]
+VARIANTS = ["w16s", "w16", "w8", "wpf", "generic"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -69,10 +73,47 @@ def test_mfcc_matches_golden(name, variant, gpu):
     mfcc_close(got, exp["mfcc"], f"{name} {variant}")
 
 
+@pytest.mark.parametrize("n", [4, 8, 160, 252, 256, 260, 512, 10236, 10240, 10244, 16000, 40964])
+def test_staged_kernel_lengths(n, gpu):
+    """The staged-sample kernel (w16s) on lengths around its edges (clip shorter than the centre pad,
+    exactly one tile of 64 frames, one frame more / fewer), several clips per launch so that tiles of
+    different clips follow each other in one workgroup: == direct-load kernel == oracle."""
+    kw, _, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    assert plan.kernel_path == "radix16-w16s"
+    clips = np.stack([O.synth_clip(700 + n + i, n, 16000, k) for i, k in enumerate(["am", "noise", "am", "noise", "impulse"])])
+    d = _dev(clips, gpu)
+    got = plan.mfcc(d).cpu().numpy()
+    P = plan.stft_power(d).cpu().numpy()
+    with _variant(plan, "w16"):
+        ref = plan.mfcc(d).cpu().numpy()
+        Pr = plan.stft_power(d).cpu().numpy()
+    np.testing.assert_allclose(P, Pr, rtol=1e-5, atol=1e-6 * max(Pr.max(), 1e-30))
+    for i in range(clips.shape[0]):
+        want = O.mfcc(clips[i], O.OracleConfig(**kw))
+        mfcc_close(got[i], want, f"w16s n={n} clip {i}")
+        mfcc_close(ref[i], want, f"w16 n={n} clip {i}")
+
+
+def test_staged_kernel_large_hop(gpu):
+    """hop 240 needs four 16-byte groups per thread (NR = 4); hop 200 with n_fft 512 / win 512."""
+    for hop, win in ((240, 480), (200, 512), (184, 400), (188, 400)):
+        kw = dict(sr=16000, n_fft=512, win_length=win, hop_length=hop, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0)
+        plan = _plan(kw)
+        assert plan.kernel_path == "radix16-w16s"
+        clips = np.stack([O.synth_clip(900 + hop + i, 48000, 16000, "am") for i in range(3)])
+        got = plan.mfcc(_dev(clips, gpu)).cpu().numpy()
+        for i in range(3):
+            mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw)), f"hop {hop} clip {i}")
+
+
 def test_kernel_variants_selected(gpu):
     kw, _, _ = load_golden("c1_am")
-    assert _plan(kw).kernel_path == "radix16-w16"
-    assert _plan(load_golden("refdefault_am")[0]).kernel_path == "radix16-w16"
+    assert _plan(kw).kernel_path == "radix16-w16s"
+    assert _plan(load_golden("refdefault_am")[0]).kernel_path == "radix16-w16s"
+    assert _plan({**kw, "hop_length": 256}).kernel_path == "radix16-w16"   # 63*hop + 512 samples > 64 KB of LDS
+    with _variant(_plan(kw), "w16"):
+        assert _plan(kw).kernel_path == "radix16-w16"
     assert _plan({**kw, "n_mels": 256}).kernel_path == "radix16-w8"      # mel table too big for w16
     assert _plan(load_golden("c4_am")[0]).kernel_path == "radix16-wpf"     # n_fft 2048: wave-per-frame kernel
     assert _plan(load_golden("odd_22k")[0]).kernel_path == "radix16-wpf"   # n_fft 1024, even hop
