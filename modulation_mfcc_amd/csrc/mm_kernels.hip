@@ -20,6 +20,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "mm_internal.h"
 
@@ -299,6 +300,7 @@ struct mm_plan {
   size_t w16_lds_bytes;
   int s16_nr;                      // staged-sample variant: 16-byte groups per thread and tile (0: not usable)
   size_t s16_lds_bytes;
+
   float *d_k2_lane_tab, *d_k2_mel_lane;   // wave-per-frame-group kernel (n_fft 512 / 1024 / 2048)
   float* d_rf2k_lane_tab;                 // rfft_wpf_kernel<4> (stage-isolated rFFT, n = 2048)
   int rf2k_ok;
@@ -473,6 +475,35 @@ static void interleave_run_groups(float* grp, size_t n_groups) {
   }
 }
 
+// The 16 waves of the fused kernels sit on 4 SIMDs (wave w on SIMD w % 4) and the mel phase is bound by
+// instruction issue per SIMD (tools/stamps.py), so which wave walks which part of the run table matters:
+// hand the parts out heaviest first to the least loaded SIMD (cost model: ~58 instructions per run +
+// ~8.5 per 4-bin group), heavier parts on the older (= favoured) wave of a SIMD.
+static std::vector<int> balance_parts_over_simds(const mm::MelRuns& r) {
+  const int n = (int)(r.part.size() / 4);
+  std::vector<int> out(r.part.size());
+  if (n != 16) return r.part;
+  std::vector<std::pair<double, int>> cost(n);
+  for (int w = 0; w < n; ++w) {
+    double c = 0;
+    for (int i = r.part[w * 4 + 0]; i < r.part[w * 4 + 1]; ++i) c += 58.0 + 8.5 * r.hdr[4 * i + 1];
+    cost[w] = {c, w};
+  }
+  std::sort(cost.begin(), cost.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+    return a.first > b.first || (a.first == b.first && a.second < b.second); });
+  double load[4] = {0, 0, 0, 0};
+  int cnt[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    int best = -1;
+    for (int sd = 0; sd < 4; ++sd)
+      if (cnt[sd] < 4 && (best < 0 || load[sd] < load[best])) best = sd;
+    const int wave = best + 4 * cnt[best];
+    std::memcpy(&out[wave * 4], &r.part[cost[i].second * 4], 16);
+    load[best] += cost[i].first; ++cnt[best];
+  }
+  return out;
+}
+
 // Per-lane constants of the wpf transform (mm_wpf.hip.inc) for n = 512*R: window (or zeros when
 // win == nullptr: the plain rFFT kernel does not read it) | W_NC^(l*k1) | W_L^(p*j) | split twiddles.
 static std::vector<float> wpf_lane_table(int R, const float* win, const float* tw) {
@@ -519,6 +550,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_mel_w = nullptr; p->d_dct_t = nullptr;
   p->d_sw_tab = nullptr; p->d_sw_part = nullptr;
   p->d_w16_tab = p->d_lane_tab = nullptr; p->d_w16_part = nullptr; p->w16_ok = 0; p->s16_nr = 0; p->s16_lds_bytes = 0;
+
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->num_cus = 256;
@@ -607,7 +639,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       if (p->w16_lds_bytes <= MM_LM_LDS_MAX &&
           upload(&p->d_w16_tab, tab16.data(), tab16.size() * 4) == MM_OK &&
           upload(&p->d_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
-          upload(&p->d_w16_part, r16.part.data(), r16.part.size() * 4) == MM_OK &&
+          upload(&p->d_w16_part, balance_parts_over_simds(r16).data(), r16.part.size() * 4) == MM_OK &&
           hipFuncSetAttribute((const void*)logmel512w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               MM_LM_LDS_MAX) == hipSuccess &&
           hipFuncSetAttribute((const void*)logmel512w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -704,6 +736,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_dct_t);
   (void)hipFree(p->d_sw_tab); (void)hipFree(p->d_sw_part);
   (void)hipFree(p->d_w16_tab); (void)hipFree(p->d_lane_tab); (void)hipFree(p->d_w16_part);
+
   (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane);
   (void)hipFree(p->d_rf2k_lane_tab);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
