@@ -189,7 +189,10 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    plan.timing_enable(True)
+    # HIP events around the dominant kernel only inside the timed region (two hipEventRecord per timed
+    # launch cost ~5 us of stream time: all four kernels timed = 4 % of a step); the other kernels'
+    # durations come from a short untimed pass afterwards
+    plan.timing_enable(True, stages=["logmel"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -201,6 +204,15 @@ def main():
     dt = time.perf_counter() - t0
     plan.timing_enable(False)
     stage = plan.timing_read()
+    plan.timing_enable(True)
+    for _ in range(min(a.steps, 5)):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    plan.timing_enable(False)
+    for k, v in plan.timing_read().items():
+        if k != "logmel":
+            stage[k] = v
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -167,6 +167,8 @@ int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t a
                int32_t frame_length, int32_t hop_length, int32_t center, float* d_rms, void* stream);
 
 /* ---- per-kernel device timing (hipEvents on the launch stream) ------------------------- */
+/* on = 0: off; 1: every stage; otherwise a mask with bit (MM_STAGE_x + 1) set for each stage to time
+ * (two hipEventRecord per timed launch: timing fewer stages perturbs the stream less). */
 int mm_timing_enable(mm_plan* plan, int on);
 /* synchronises the recorded events; ms_sum[s]/count[s] = average launch duration of stage s;
  * resets the accumulators. Arrays of MM_NUM_STAGES. */

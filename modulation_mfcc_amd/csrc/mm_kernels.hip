@@ -324,6 +324,7 @@ struct StageTimer {
   int idx;
   StageTimer(mm_plan* plan, int stage, hipStream_t stream) : p(plan), s(stream), idx(-1) {
     if (!p->timing_on || p->ev_used >= MM_MAX_TIMED) return;
+    if (p->timing_on != 1 && !((p->timing_on >> (stage + 1)) & 1)) return;   // stage mask
     if ((size_t)(2 * p->ev_used + 1) >= p->ev_pool.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -1124,7 +1125,7 @@ int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t s
 
 int mm_timing_enable(mm_plan* p, int on) {
   if (!p) return MM_ERR_INVALID_ARG;
-  p->timing_on = on ? 1 : 0;
+  p->timing_on = on;
   return MM_OK;
 }
 

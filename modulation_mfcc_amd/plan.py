@@ -293,8 +293,15 @@ class MfccPlan:
         return out
 
     # ---- per-kernel device timing -------------------------------------------------------
-    def timing_enable(self, on=True):
-        _lib.check(self._lib.mm_timing_enable(self._h, 1 if on else 0), "mm_timing_enable")
+    def timing_enable(self, on=True, stages=None):
+        """Record hipEvents around the library's launches; `stages` (names from _lib.STAGES) limits
+        the recording to those kernels."""
+        flag = 1 if on else 0
+        if on and stages:
+            flag = 0
+            for name in stages:
+                flag |= 1 << (_lib.STAGES.index(name) + 1)
+        _lib.check(self._lib.mm_timing_enable(self._h, flag), "mm_timing_enable")
 
     def timing_read(self):
         """{stage: (total_ms, launches)} since the last read (synchronises the recorded events)."""
