@@ -1052,12 +1052,14 @@ static int change_pads(int n_sec1, const double* sos1, int n_sec2, const double*
   return make_sosfilt(sos2, n_sec2, f2);
 }
 
+static int64_t round64(int64_t v) { return (v + 63) / 64 * 64; }
+
 size_t mm_change_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_frames) {
   if (!p || batch < 1 || n_frames < 1) return 0;
-  // worst case padding: 3 * (2 * MM_MAX_SEC + 1) on both sides
+  // two time-major buffers [T + 2 pad][columns padded to 64]; worst-case padding 3 * (2 * MM_MAX_SEC + 1)
   const int64_t padmax = 3 * (2 * MM_MAX_SEC + 1);
   const int64_t n = n_frames + 2 * padmax;
-  return (size_t)batch * ((size_t)p->cfg.n_mfcc * n + 2 * n) * sizeof(double);
+  return (size_t)n * (size_t)(round64(batch * p->cfg.n_mfcc) + round64(batch)) * sizeof(double);
 }
 
 int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_frames,
@@ -1066,17 +1068,35 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   if (!p || !d_mfcc || !d_change || !d_ws || batch < 1 || n_frames < 1) return MM_ERR_INVALID_ARG;
   if (remove_first < 0 || remove_first >= p->cfg.n_mfcc) return MM_ERR_INVALID_ARG;
   if (batch > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  ChangeParams q;
-  int rc = change_pads(n_sec1, sos1, n_sec2, sos2, &q.f1, &q.f2);
+  SosFilt f1, f2;
+  int rc = change_pads(n_sec1, sos1, n_sec2, sos2, &f1, &f2);
   if (rc) return rc;
   // scipy: "The length of the input vector x must be greater than padlen"
-  if (n_frames <= q.f1.padlen || n_frames <= q.f2.padlen) return MM_ERR_INVALID_ARG;
+  if (n_frames <= f1.padlen || n_frames <= f2.padlen) return MM_ERR_INVALID_ARG;
   if (ws_bytes < mm_change_workspace_bytes(p, batch, n_frames)) return MM_ERR_WORKSPACE;
-  q.mfcc = d_mfcc; q.n_frames = n_frames; q.n_mfcc = p->cfg.n_mfcc; q.first_row = remove_first ? 1 : 0;
-  q.ws = (double*)d_ws; q.out = d_change;
+  ChangeParams q;
+  q.mfcc = d_mfcc; q.n_frames = n_frames; q.batch = batch; q.n_mfcc = p->cfg.n_mfcc;
+  q.first_row = remove_first ? 1 : 0; q.n_rows = q.n_mfcc - q.first_row;
+  q.p1 = f1.padlen; q.p2 = f2.n_sec > 0 ? f2.padlen : 0;
+  q.R = batch * q.n_rows; q.Rp = round64(q.R); q.Bp = round64(batch);
+  const int64_t n1 = n_frames + 2 * q.p1, n2 = n_frames + 2 * q.p2;
+  q.ws1 = (double*)d_ws; q.ws2 = q.ws1 + n1 * q.Rp; q.out = d_change;
+  const int64_t tblocks = (n_frames + 63) / 64;
+  if (tblocks > 65535 || 2 * (int64_t)q.p1 * q.Rp / 256 + 1 > 0x7FFFFFFF || n_frames * q.Bp / 256 + 1 > 0x7FFFFFFF)
+    return MM_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   StageTimer tm(p, MM_STAGE_CHANGE, st);
-  hipLaunchKernelGGL(mfcc_change_kernel, dim3((unsigned)batch), dim3(64), 0, st, q);
+  hipLaunchKernelGGL(chg_pack_kernel, dim3((unsigned)(q.Rp / 64), (unsigned)tblocks), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p1 * q.Rp + 255) / 256)), dim3(256), 0, st,
+                     q.ws1, n_frames, q.p1, q.Rp);
+  launch_sos_any(f1, q.ws1, n1, q.Rp, st);
+  hipLaunchKernelGGL(chg_norm_kernel, dim3((unsigned)((n_frames * q.Bp + 255) / 256)), dim3(256), 0, st, q);
+  if (f2.n_sec > 0) {
+    hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p2 * q.Bp + 255) / 256)), dim3(256), 0, st,
+                       q.ws2, n_frames, q.p2, q.Bp);
+    launch_sos_any(f2, q.ws2, n2, q.Bp, st);
+  }
+  hipLaunchKernelGGL(chg_unpack_kernel, dim3((unsigned)(q.Bp / 64), (unsigned)tblocks), dim3(256), 0, st, q);
   HIP_TRY(hipGetLastError());
   return MM_OK;
 }
