@@ -1122,6 +1122,45 @@ __global__ __launch_bounds__(256) void rms_frames_kernel(const float* __restrict
   if (lane == 0) out[w] = sqrtf(acc / (float)frame_length);
 }
 
+// Tiled variant: a workgroup squares the (F-1)*hop + frame_length samples of F consecutive frames of
+// one clip into LDS once (frames overlap frame_length/hop times), then every wave sums whole frames
+// from LDS in the same order as rms_frames_kernel (lane-strided, then a butterfly): same bits, each
+// sample read from global memory ~once instead of frame_length/hop times.
+__global__ __launch_bounds__(256) void rms_tile_kernel(const float* __restrict__ audio, int64_t n_samples,
+                                                       int64_t stride, int frame_length, int hop, int pad,
+                                                       int64_t n_out, int frames_per_tile, int64_t tiles_per_clip,
+                                                       float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float rms_sq[];
+  float* sq = rms_sq;
+  const int64_t b = blockIdx.x / tiles_per_clip, tile = blockIdx.x - b * tiles_per_clip;
+  const int64_t t0 = tile * frames_per_tile;
+  const int nf = (int)((n_out - t0) < frames_per_tile ? (n_out - t0) : frames_per_tile);
+  const int span = (nf - 1) * hop + frame_length;
+  const float* a = audio + b * stride;
+  const int64_t start = t0 * hop - pad;
+  for (int j0 = threadIdx.x; j0 < span; j0 += 1024) {   // four independent loads in flight per thread
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = start + j0 + 256 * u;
+      v[u] = (i >= 0 && i < n_samples && j0 + 256 * u < span) ? a[i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j0 + 256 * u < span) sq[j0 + 256 * u] = v[u] * v[u];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int f = wave; f < nf; f += 4) {
+    const float* s = sq + f * hop;
+    float acc = 0.0f;
+    for (int j = lane; j < frame_length; j += 64) acc += s[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[b * n_out + t0 + f] = sqrtf(acc / (float)frame_length);
+  }
+}
+
 int64_t mm_rms_num_frames(int64_t n_samples, int32_t frame_length, int32_t hop_length, int32_t center) {
   if (n_samples < 1 || frame_length < 1 || hop_length < 1) return MM_ERR_INVALID_ARG;
   const int64_t padded = n_samples + (center ? 2 * (int64_t)(frame_length / 2) : 0);
@@ -1135,6 +1174,23 @@ int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t s
   const int64_t n_out = mm_rms_num_frames(n_samples, frame_length, hop_length, center);
   if (n_out < 0) return (int)n_out;
   const int64_t total = batch * n_out;
+  // tiled kernel: ~16 frames per workgroup (small tiles keep many workgroups per CU in flight), LDS
+  // between 16 and 64 KB
+  int64_t want = (int64_t)frame_length + 15 * (int64_t)hop_length;
+  const int lds_floats = (int)(want < 4096 ? 4096 : (want > 16384 ? 16384 : want));
+  if (frame_length <= lds_floats) {
+    int64_t fpt = (lds_floats - frame_length) / hop_length + 1;
+    if (fpt > 64) fpt = 64;
+    if (fpt > n_out) fpt = n_out;
+    const int64_t tpc = (n_out + fpt - 1) / fpt;
+    if (batch * tpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+    const size_t lds = (size_t)((fpt - 1) * hop_length + frame_length) * 4;
+    hipLaunchKernelGGL(rms_tile_kernel, dim3((unsigned)(batch * tpc)), dim3(256), lds, (hipStream_t)stream, d_audio,
+                       n_samples, stride, frame_length, hop_length, center ? frame_length / 2 : 0, n_out, (int)fpt, tpc,
+                       d_rms);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
   const int64_t grid = (total + 3) / 4;
   if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(rms_frames_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_audio,

@@ -426,7 +426,9 @@ def test_random_configs_match_oracle(idx, gpu):
 
 
 @pytest.mark.parametrize("n,fl,hop,center", [(4000, 400, 80, True), (4000, 401, 77, True), (1600, 1600, 160, False),
-                                              (50, 400, 80, True), (16000, 1600, 160, True)])
+                                              (50, 400, 80, True), (16000, 1600, 160, True),
+                                              (48000, 2048, 160, True), (40000, 16384, 1, False),
+                                              (70000, 20000, 4000, True)])
 def test_rms_frames_on_device(n, fl, hop, center, gpu):
     """Row N3: mm_rms_f32 == librosa.feature.rms(center, pad_mode='constant') (script/calc.py:331)."""
     from modulation_mfcc_amd import rms_batch
