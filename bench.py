@@ -119,6 +119,10 @@ def main():
     ap.add_argument("--clips", type=int, default=0, help="override clips per GPU (debug)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic kernels")
+    ap.add_argument("--gather", default="mfcc", choices=["mfcc", "full"],
+                    help="N > 1: 'mfcc' gathers the MFCC slab and the root computes the modulation spectrum of the "
+                         "gathered trajectories (default: half the bytes over xGMI); 'full': every rank computes its "
+                         "own modulation spectrum and both arrays are gathered")
     a = ap.parse_args()
 
     # Anything libraries print on stdout (RCCL prints a version banner there at communicator init)
@@ -164,20 +168,32 @@ def main():
     # one flat output slab per rank so that a single gather per step moves everything; with N > 1
     # the slabs are double-buffered and the gather of step k runs on a side stream under the
     # kernels of step k+1 (every step's gather still completes inside the timed region)
-    lay = SlabLayout.make(cfg, B, n, with_mod)
-    n_mod = lay.n_mod
+    # N > 1, --gather mfcc: the modulation spectrum is a linear map of the MFCC trajectories, so only
+    # the MFCC slab travels and the root runs ONE trajectory rFFT over the gathered block on the
+    # gather's side stream (modulation_mfcc_amd/dist.py)
+    mod_on_root = use_dist and with_mod and a.gather == "mfcc"
+    lay = SlabLayout.make(cfg, B, n, with_mod and not mod_on_root)
+    n_mod = cfg.mod_fft_len(T) if with_mod else 0
     pg = PipelinedGather(lay.numel, dev) if use_dist else None
     slab1 = torch.empty(lay.numel, dtype=torch.float32, device=dev) if not use_dist else None
     plan.workspace(B, n)
+    mod_all = None
+    if mod_on_root and rank == 0:
+        mod_all = [torch.empty((world * B, cfg.n_mfcc, n_mod // 2 + 1), dtype=torch.complex64, device=dev)
+                   for _ in range(pg.depth)]
+
+    def root_modspec(i):        # runs inside the gather's side stream, root only
+        got = pg.recv_block[i][:, :lay.mfcc_numel].reshape(world * B, cfg.n_mfcc, T)
+        plan.modspec(got, out=mod_all[i])
 
     def step():
         slab = pg.acquire() if pg else slab1
         mfcc_out, mod_out = lay.views(slab)
         plan.mfcc(audio, out=mfcc_out)
-        if with_mod:
+        if with_mod and not mod_on_root:
             plan.modspec(mfcc_out, out=mod_out)
         if pg:
-            pg.submit()
+            pg.submit(post=root_modspec if mod_on_root else None)
 
     def drain():
         if pg:
@@ -229,7 +245,8 @@ def main():
                                f"n_fft {cfg.n_fft}, {cfg.n_mels} mel, {cfg.n_mfcc} MFCC"
                                + (f" + modulation spectrum (rFFT {n_mod} over trajectories)" if with_mod else ""),
                    "frames_per_clip": T, "clips_total": world * B, "kernel_path": plan.kernel_path,
-                   "parallelism": f"clips sharded x{world}" + (", one RCCL gather per step (overlapped with the next step's kernels)" if world > 1 else "")},
+                   "parallelism": f"clips sharded x{world}" + (", one RCCL gather per step (overlapped with the next step's kernels)" if world > 1 else "")
+                                  + ("; MFCC slab gathered, modulation spectrum of the gathered trajectories computed on the root" if mod_on_root else "")},
     }
 
     if rank == 0:

@@ -3,8 +3,16 @@ ROCm, over xGMI), ONE gather of the per-rank output slab to the root at the end.
 
 Clips are independent (every reduction of the hot path -- the per-clip top_db max, the trajectory
 rFFT -- stays inside a clip), so there is no mid-pipeline exchange: rank r computes
-its contiguous block of clips and the only collective is the final gather.  MFCC and modulation
-spectrum share one flat float32 slab per rank so that a single collective moves both.
+its contiguous block of clips and the only collective is the final gather.
+
+What travels: the modulation spectrum is a fixed linear map (zero-padded rFFT) of the MFCC
+trajectories, i.e. pure redundancy on the wire -- as many bytes again as the MFCCs themselves, over
+point-to-point xGMI links whose ~50 GB/s per direction make the gather, not the kernels, the slow
+part of a step at N >= 2.  By default (``modspec_on_root=True``) only the MFCC slab is gathered and
+the root runs the trajectory rFFT over the gathered [B_total, n_mfcc, T] block (one launch, ~0.3 ms
+for 8192 clips); ``modspec_on_root=False`` is the literal variant: every rank computes its own
+modulation spectrum and MFCC + modulation spectrum share one flat float32 slab per rank so that a
+single collective moves both.
 """
 from __future__ import annotations
 
@@ -98,8 +106,10 @@ class PipelinedGather:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.slabs = [torch.empty(numel, dtype=torch.float32, device=device) for _ in range(depth)]
-        self.received = [[torch.empty(numel, dtype=torch.float32, device=device) for _ in range(self.world)]
-                         if self.rank == dst else None for _ in range(depth)]
+        # root: one contiguous [world, numel] block per buffer (the per-rank receive tensors are its rows)
+        self.recv_block = [torch.empty((self.world, numel), dtype=torch.float32, device=device)
+                           if self.rank == dst else None for _ in range(depth)]
+        self.received = [list(blk.unbind(0)) if blk is not None else None for blk in self.recv_block]
         self.stream = torch.cuda.Stream(device=device)
         self.ev_done = [torch.cuda.Event() for _ in range(depth)]     # gather of buffer i finished
         self.ev_ready = [torch.cuda.Event() for _ in range(depth)]    # kernels of buffer i finished
@@ -113,13 +123,18 @@ class PipelinedGather:
             torch.cuda.current_stream().wait_event(self.ev_done[i])
         return self.slabs[i]
 
-    def submit(self):
+    def submit(self, post=None):
+        """Gather the current slab on the side stream; ``post(i)`` (root only) is called inside the side
+        stream's context right after it, e.g. to run the root-side modulation spectrum on
+        ``recv_block[i]``."""
         import torch
         i = self.k % self.depth
         self.ev_ready[i].record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(self.ev_ready[i])
             gather_slabs(self.slabs[i], dst=self.dst, group=self.group, out=self.received[i])
+            if post is not None and self.rank == self.dst:
+                post(i)
             self.ev_done[i].record(self.stream)
         self._used[i] = True
         self.k += 1
@@ -130,13 +145,16 @@ class PipelinedGather:
 
 
 def mfcc_modspec_sharded(audio_all_or_local, cfg: MfccConfig, *, with_modspec=True, dst=0, group=None,
-                         is_local=False, compute=None):
+                         is_local=False, compute=None, modspec_on_root=True, root_modspec=None):
     """Run the hot path on this rank's clips and gather everything on ``dst``.
 
     audio_all_or_local  [B_total, n] (every rank holds or can index the full batch) or, with
                         is_local=True, this rank's own [B_local, n] block
     compute             callable(audio_local, layout, slab) filling ``slab``; defaults to the HIP
                         plan (tests inject a CPU stand-in to exercise the collective under gloo)
+    modspec_on_root     gather the MFCCs only and compute the modulation spectrum of the gathered block
+                        on ``dst`` (see the module docstring); False: every rank sends both
+    root_modspec        callable(mfcc_all) -> modspec for the root-side variant (default: the HIP plan)
     Returns on dst: (mfcc [B_total, n_mfcc, T], modspec or None); elsewhere (None, None).
     """
     import torch
@@ -156,16 +174,18 @@ def mfcc_modspec_sharded(audio_all_or_local, cfg: MfccConfig, *, with_modspec=Tr
         local = audio_all_or_local[s:e]
     n = local.shape[1]
     bmax = max(counts)
-    lay = SlabLayout.make(cfg, bmax, n, with_modspec)          # equal-size slabs (padded shards)
+    on_root = bool(with_modspec and modspec_on_root)
+    send_mod = with_modspec and not on_root
+    lay = SlabLayout.make(cfg, bmax, n, send_mod)              # equal-size slabs (padded shards)
     slab = torch.zeros(lay.numel, dtype=torch.float32, device=local.device)
     if local.shape[0]:
-        lay_local = SlabLayout.make(cfg, local.shape[0], n, with_modspec)
+        lay_local = SlabLayout.make(cfg, local.shape[0], n, send_mod)
         if compute is None:
             from .plan import get_plan
             plan = get_plan(cfg)
             m, ms = lay.views(slab)
             plan.mfcc(local, out=m[:local.shape[0]])
-            if with_modspec:
+            if send_mod:
                 plan.modspec(m[:local.shape[0]], out=ms[:local.shape[0]])
         else:
             compute(local, lay_local, lay, slab)
@@ -176,6 +196,12 @@ def mfcc_modspec_sharded(audio_all_or_local, cfg: MfccConfig, *, with_modspec=Tr
     for r, g in enumerate(got):
         m, ms = lay.views(g)
         ms_all.append(m[:counts[r]])
-        if with_modspec:
+        if send_mod:
             mod_all.append(ms[:counts[r]])
-    return torch.cat(ms_all, 0), (torch.cat(mod_all, 0) if with_modspec else None)
+    mfcc_all = torch.cat(ms_all, 0)
+    if on_root:
+        if root_modspec is None:
+            from .plan import get_plan
+            root_modspec = get_plan(cfg).modspec
+        return mfcc_all, root_modspec(mfcc_all)
+    return mfcc_all, (torch.cat(mod_all, 0) if with_modspec else None)

@@ -37,11 +37,15 @@ def main():
     audio = torch.from_numpy(clips)
     cfg = MfccConfig(**KW)
     assert shard_bounds(n_clips, world)[-1][1] == n_clips
-    for is_local in (False, True):
+    def root_modspec(mfcc_all):        # CPU stand-in of plan.modspec for the root-side variant
+        return torch.from_numpy(np.stack([O.modspec(x) for x in mfcc_all.numpy()]))
+
+    for is_local, on_root in ((False, False), (True, False), (False, True), (True, True)):
         s, e = shard_bounds(n_clips, world)[rank]
         arg = audio[s:e] if is_local else audio
         m, ms = mfcc_modspec_sharded(arg, cfg, with_modspec=True, dst=0, is_local=is_local,
-                                     compute=oracle_compute)
+                                     compute=oracle_compute, modspec_on_root=on_root,
+                                     root_modspec=root_modspec)
         if rank == 0:
             ocfg = O.OracleConfig(**KW)
             want = np.stack([O.mfcc(c, ocfg) for c in clips])
