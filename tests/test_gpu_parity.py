@@ -483,3 +483,65 @@ def test_calls_are_graph_capturable(gpu):
     want = plan.mfcc(_dev(clips[::-1].copy(), gpu))
     assert torch.equal(m, want)
     assert torch.equal(ms, plan.modspec(want))
+
+
+def test_sharded_driver_single_rank_nccl(gpu):
+    """The N > 1 code path (process group on RCCL, slab layout, gather, root-side modulation spectrum,
+    the double-buffered PipelinedGather with its post hook) with a single-rank group: everything but
+    the wire.  world_size-2 arithmetic is covered on CPU by tests/test_dist_gloo.py."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from modulation_mfcc_amd import MfccConfig
+    from modulation_mfcc_amd.dist import PipelinedGather, SlabLayout, mfcc_modspec_sharded
+    kw, _, _ = load_golden("c1_am")
+    cfg = MfccConfig(**kw)
+    plan = _plan(kw)
+    clips = np.stack([O.synth_clip(40 + i, 16000, 16000, "am") for i in range(5)])
+    d = _dev(clips, gpu)
+    want_m = plan.mfcc(d)
+    want_ms = plan.modspec(want_m)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29641"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    try:
+        for on_root in (True, False):
+            m, ms = mfcc_modspec_sharded(d, cfg, with_modspec=True, modspec_on_root=on_root)
+            assert torch.equal(m, want_m) and torch.equal(ms, want_ms)
+        T = cfg.num_frames(16000)
+        lay = SlabLayout.make(cfg, 5, 16000, False)
+        pg = PipelinedGather(lay.numel, gpu)
+        mod_all = [torch.empty_like(want_ms) for _ in range(pg.depth)]
+
+        def post(i):
+            plan.modspec(pg.recv_block[i][:, :lay.mfcc_numel].reshape(5, cfg.n_mfcc, T), out=mod_all[i])
+
+        for k in range(5):                          # more steps than buffers
+            slab = pg.acquire()
+            mv, _ = lay.views(slab)
+            plan.mfcc(d, out=mv)
+            pg.submit(post=post)
+        pg.finish()
+        torch.cuda.synchronize()
+        for i in range(pg.depth):
+            assert torch.equal(pg.recv_block[i][0, :lay.mfcc_numel].view_as(want_m), want_m)
+            assert torch.equal(mod_all[i], want_ms)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_timing_stage_mask(gpu):
+    kw, y, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    d = _dev(y, gpu)[None, :]
+    plan.timing_enable(True, stages=["dct"])
+    m = plan.mfcc(d)
+    plan.modspec(m)
+    plan.timing_enable(False)
+    got = plan.timing_read()
+    assert set(got) == {"dct"} and got["dct"][1] == 1
+    plan.timing_enable(True)
+    plan.modspec(plan.mfcc(d))
+    plan.timing_enable(False)
+    assert {"logmel", "dct", "modspec"} <= set(plan.timing_read())
