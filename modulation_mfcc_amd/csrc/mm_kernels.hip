@@ -304,7 +304,7 @@ struct mm_plan {
   float *d_k2_lane_tab, *d_k2_mel_lane;   // wave-per-frame-group kernel (n_fft 512 / 1024 / 2048)
   float* d_rf2k_lane_tab;                 // rfft_wpf_kernel<4> (stage-isolated rFFT, n = 2048)
   int rf2k_ok;
-  int k2_ok, wpf_r, wpf_waves;
+  int k2_ok, wpf_r, wpf_waves, wpf_group_max;
   size_t wpf_lds_bytes;
   int num_cus;
   // timing
@@ -669,6 +669,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     mm::MelSweep sw2;
     if (mm::build_mel_sweep(*cfg, mel.data(), 1, &sw2)) {
       std::vector<float> ml((size_t)L * 36, 0.0f);
+      std::vector<int> d_end(L, -2);
       bool ok = true;
       for (int l = 0; l < L && ok; ++l) {
         float* r = ml.data() + l * 36;
@@ -687,7 +688,37 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         }
         std::memcpy(&r[34], &dstart, 4);
         std::memcpy(&r[35], &bits, 4);
+        d_end[l] = dprev;
       }
+      // lanes whose sweep ends in the same run form a contiguous group: distance to its first lane in
+      // bits 20..22 of the flag word, "last lane of the group" in bit 23 (the kernel pre-sums a group
+      // in registers, at most 8 lanes)
+      // (lanes whose remaining weights are all zero -- bins above fmax -- take no part)
+      std::vector<char> act(L, 0);
+      for (int l = 0; l < L; ++l) {
+        const float* r = ml.data() + (size_t)l * 36;
+        unsigned bits;
+        std::memcpy(&bits, &r[35], 4);
+        int from = 0;
+        for (int i = 0; i < 17; ++i) if ((bits >> i) & 1u) from = i;
+        for (int i = from; i < 17; ++i) if (r[i] != 0.0f || r[17 + i] != 0.0f) act[l] = 1;
+      }
+      int group_max = 0;
+      for (int l = 0; l < L && ok; ++l) {
+        if (!act[l]) continue;
+        int first = l;
+        while (first > 0 && act[first - 1] && d_end[first - 1] == d_end[l]) --first;
+        const int dist = l - first;
+        const bool last = (l == L - 1) || !act[l + 1] || d_end[l + 1] != d_end[l];
+        if (dist > 7) { ok = false; break; }
+        group_max = std::max(group_max, dist);
+        unsigned bits;
+        std::memcpy(&bits, &ml[(size_t)l * 36 + 35], 4);
+        bits |= (unsigned)dist << 20;
+        if (last) bits |= 1u << 23;
+        std::memcpy(&ml[(size_t)l * 36 + 35], &bits, 4);
+      }
+      p->wpf_group_max = group_max;
       std::vector<float> lt = wpf_lane_table(R, win.data(), tw.data());
       const int macc_stride = (cfg->n_mels + 63) / 64 * 64;
       const int F = 4 / R;
@@ -794,7 +825,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.total_groups = batch * q.groups_per_clip;
     q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
     q.macc_stride = (p->cfg.n_mels + 63) / 64 * 64; q.waves_per_wg = p->wpf_waves;
-    q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane;
+    q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane; q.group_max = p->wpf_group_max;
     q.out_logmel = out_logmel; q.clip_key = clip_key; q.out_power = out_power;
     if (frame_major) { q.sB = q.n_frames * q.n_mels; q.sT = q.n_mels; q.sM = 1; }
     else { q.sB = q.n_frames * q.n_mels; q.sT = 1; q.sM = q.n_frames; }
