@@ -318,6 +318,13 @@ struct mm_plan {
 
 namespace {
 
+// development switches (tools/README.md): MM_PATH pins a fused-kernel variant, MM_DEBUG is the ablation
+// mask of the direct-load 16-wave kernel; read per call so that tests can flip them
+static int dev_env(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+
 struct StageTimer {
   mm_plan* p;
   hipStream_t s;
@@ -785,10 +792,10 @@ int mm_plan_config(const mm_plan* p, mm_config* out) {
 int mm_plan_kernel_path(const mm_plan* p) {
   if (!p) return MM_ERR_INVALID_ARG;
   if (p->force_generic) return 0;
-  const bool force_wpf = getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 3;
+  const bool force_wpf = dev_env("MM_PATH") == 3;
   if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1)) return 3;
   if (p->path == 1 && p->w16_ok) {
-    const int mp = getenv("MM_PATH") ? atoi(getenv("MM_PATH")) : 0;
+    const int mp = dev_env("MM_PATH");
     if (mp == 1) return 1;
     return (p->s16_nr && mp != 2) ? 4 : 2;
   }
@@ -814,7 +821,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
                        int64_t stride, float* out_power, float* out_logmel, int* clip_key,
                        hipStream_t st, bool frame_major = false, bool* is_fm = nullptr) {
   if (is_fm) *is_fm = false;
-  const bool force_wpf = getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 3;
+  const bool force_wpf = dev_env("MM_PATH") == 3;
   if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1) && !p->force_generic &&
       (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2) {
     WpfParams q;
@@ -853,15 +860,15 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.window = p->d_window; q.tw = p->d_tw; q.mel_tab = (const float4*)p->d_sw_tab; q.n_runs = p->sw_n_runs; q.n_tab16 = p->sw_n_tab16;
     q.wave_part = p->d_sw_part; q.out_logmel = out_logmel; q.clip_key = clip_key;
     q.out_power = out_power;
-    q.dbg = getenv("MM_DEBUG") ? atoi(getenv("MM_DEBUG")) : 0;
+    q.dbg = dev_env("MM_DEBUG");
     q.lane_tab = p->d_lane_tab;
     const int64_t grid = q.n_tiles < p->num_cus ? q.n_tiles : p->num_cus;
-    const bool use_w16 = p->w16_ok && !(getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 1);
+    const bool use_w16 = p->w16_ok && dev_env("MM_PATH") != 1;
     if (use_w16) {
       q.mel_tab = (const float4*)p->d_w16_tab; q.n_runs = p->w16_n_runs; q.n_tab16 = p->w16_n_tab16;
       q.wave_part = p->d_w16_part;
       const bool staged = p->s16_nr && (stride % 4) == 0 && (n_samples % 4) == 0 && n_samples >= 4 &&
-                          (((uintptr_t)d_audio) & 15) == 0 && !(getenv("MM_PATH") && atoi(getenv("MM_PATH")) == 2);
+                          (((uintptr_t)d_audio) & 15) == 0 && dev_env("MM_PATH") != 2;
       if (staged) {
         if (p->s16_nr == 3) {
           if (mode == 0) hipLaunchKernelGGL((logmel512s_kernel<0, 3>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
