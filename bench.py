@@ -246,7 +246,8 @@ def main():
                                + (f" + modulation spectrum (rFFT {n_mod} over trajectories)" if with_mod else ""),
                    "frames_per_clip": T, "clips_total": world * B, "kernel_path": plan.kernel_path,
                    "parallelism": f"clips sharded x{world}" + (", one RCCL gather per step (overlapped with the next step's kernels)" if world > 1 else "")
-                                  + ("; MFCC slab gathered, modulation spectrum of the gathered trajectories computed on the root" if mod_on_root else "")},
+                                  + ("; MFCC slab gathered, modulation spectrum of the gathered trajectories computed on the root" if mod_on_root else ""),
+                   "gather": (a.gather if use_dist else None)},
     }
 
     if rank == 0:
