@@ -744,8 +744,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         attr_ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
       if (ok && attr_ok && upload(&p->d_k2_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
           upload(&p->d_k2_mel_lane, ml.data(), ml.size() * 4) == MM_OK &&
-          hipFuncSetAttribute((const void*)dct_clamp_fm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              64 * (MM_WPF_MAXMEL + 1) * 4) == hipSuccess)
+          set_dct_fm_attr(64 * (MM_WPF_MAXMEL + 1) * 4))
         p->k2_ok = 1;
     }
   }
@@ -973,9 +972,8 @@ int mm_mfcc_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_sampl
     if (fm) {
       const int64_t bpc = (T + 63) / 64;
       if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-      hipLaunchKernelGGL(dct_clamp_fm_kernel, dim3((unsigned)(batch * bpc)), dim3(256),
-                         (size_t)64 * (p->cfg.n_mels + 1) * 4, st, logmel, keys, p->d_dct_t, d_mfcc, T,
-                         p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
+      launch_dct_fm(dim3((unsigned)(batch * bpc)), (size_t)64 * (p->cfg.n_mels + 1) * 4, st, logmel, keys, p->d_dct_t,
+                    d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
     } else {
       const int64_t bpc = (T + 255) / 256;
       if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
