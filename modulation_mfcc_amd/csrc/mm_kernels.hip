@@ -731,7 +731,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       const int F = 4 / R;
       const int xbuf = (R == 1) ? 1280 : 1152;
       const int pbuf = F * (NC + NC / 16 + 4);
-      const size_t wave_bytes = (size_t)(xbuf + pbuf + F * macc_stride) * 4;
+      const size_t wave_bytes = (size_t)(xbuf + pbuf + F * 3 * macc_stride) * 4;
       p->wpf_r = R;
       p->wpf_waves = 12;
       while (p->wpf_waves > 4 && (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes > MM_LM_LDS_MAX) p->wpf_waves -= 4;
