@@ -594,9 +594,10 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
       p->num_cus = prop.multiProcessorCount;
   }
-  // register radix-16 path: n_fft 512, even hop (8-byte frame loads), no pre-emphasis
+  // register radix-16 path: n_fft 512, even hop (8-byte frame loads); with pre-emphasis only the
+  // staged-sample kernel applies (it filters while staging), other calls then use the generic path
   mm::MelSweep sw;
-  if (cfg->n_fft == 512 && (cfg->hop_length % 2) == 0 && cfg->preemph == 0.0f &&
+  if (cfg->n_fft == 512 && (cfg->hop_length % 2) == 0 &&
       mm::build_mel_sweep(*cfg, mel.data(), 8, &sw)) {
     mm::MelRuns runs;
     mm::build_mel_runs(*cfg, sw, 8, &runs);
@@ -659,10 +660,12 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         const int span = 63 * cfg->hop_length + 512;
         const int nr = span <= 3 * 4096 ? 3 : (span <= 4 * 4096 ? 4 : 0);
         const size_t lds = nr ? (size_t)(nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tab16.size() * 4 : 0;
-        const void* kfn[4] = {(const void*)logmel512s_kernel<0, 3>, (const void*)logmel512s_kernel<1, 3>,
-                              (const void*)logmel512s_kernel<0, 4>, (const void*)logmel512s_kernel<1, 4>};
+        const void* kfn[8] = {(const void*)logmel512s_kernel<0, 3, false>, (const void*)logmel512s_kernel<1, 3, false>,
+                              (const void*)logmel512s_kernel<0, 4, false>, (const void*)logmel512s_kernel<1, 4, false>,
+                              (const void*)logmel512s_kernel<0, 3, true>, (const void*)logmel512s_kernel<1, 3, true>,
+                              (const void*)logmel512s_kernel<0, 4, true>, (const void*)logmel512s_kernel<1, 4, true>};
         bool ok = nr && lds <= MM_LM_LDS_MAX;
-        for (int i = 0; i < 4 && ok; ++i)
+        for (int i = 0; i < 8 && ok; ++i)
           ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
         if (ok) { p->s16_nr = nr; p->s16_lds_bytes = lds; }
       }
@@ -795,9 +798,11 @@ int mm_plan_kernel_path(const mm_plan* p) {
   if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1)) return 3;
   if (p->path == 1 && p->w16_ok) {
     const int mp = dev_env("MM_PATH");
+    if (p->cfg.preemph != 0.0f) return (p->s16_nr && mp != 1 && mp != 2) ? 4 : 0;
     if (mp == 1) return 1;
     return (p->s16_nr && mp != 2) ? 4 : 2;
   }
+  if (p->cfg.preemph != 0.0f) return 0;
   return p->path;
 }
 
@@ -848,8 +853,11 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     HIP_TRY(hipGetLastError());
     return MM_OK;
   }
+  // pre-emphasis exists only in the staged-sample kernel (applied while staging)
+  const bool staged_ok = p->s16_nr && p->w16_ok && (stride % 4) == 0 && (n_samples % 4) == 0 && n_samples >= 4 &&
+                         (((uintptr_t)d_audio) & 15) == 0 && dev_env("MM_PATH") != 2 && dev_env("MM_PATH") != 1;
   if (p->path == 1 && !p->force_generic && (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 &&
-      n_samples >= 2) {
+      n_samples >= 2 && (p->cfg.preemph == 0.0f || staged_ok)) {
     Logmel512Params q;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
     q.n_frames = mm_num_frames(&p->cfg, n_samples);
@@ -866,16 +874,18 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     if (use_w16) {
       q.mel_tab = (const float4*)p->d_w16_tab; q.n_runs = p->w16_n_runs; q.n_tab16 = p->w16_n_tab16;
       q.wave_part = p->d_w16_part;
-      const bool staged = p->s16_nr && (stride % 4) == 0 && (n_samples % 4) == 0 && n_samples >= 4 &&
-                          (((uintptr_t)d_audio) & 15) == 0 && dev_env("MM_PATH") != 2;
-      if (staged) {
+      if (staged_ok) {
+        q.preemph = p->cfg.preemph;
+        const bool pre = p->cfg.preemph != 0.0f;
+#define MM_S16_LAUNCH(MM, NN, PP) hipLaunchKernelGGL((logmel512s_kernel<MM, NN, PP>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q)
         if (p->s16_nr == 3) {
-          if (mode == 0) hipLaunchKernelGGL((logmel512s_kernel<0, 3>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
-          else hipLaunchKernelGGL((logmel512s_kernel<1, 3>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
+          if (mode == 0) { if (pre) MM_S16_LAUNCH(0, 3, true); else MM_S16_LAUNCH(0, 3, false); }
+          else { if (pre) MM_S16_LAUNCH(1, 3, true); else MM_S16_LAUNCH(1, 3, false); }
         } else {
-          if (mode == 0) hipLaunchKernelGGL((logmel512s_kernel<0, 4>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
-          else hipLaunchKernelGGL((logmel512s_kernel<1, 4>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);
+          if (mode == 0) { if (pre) MM_S16_LAUNCH(0, 4, true); else MM_S16_LAUNCH(0, 4, false); }
+          else { if (pre) MM_S16_LAUNCH(1, 4, true); else MM_S16_LAUNCH(1, 4, false); }
         }
+#undef MM_S16_LAUNCH
         HIP_TRY(hipGetLastError());
         return MM_OK;
       }

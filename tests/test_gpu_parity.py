@@ -106,6 +106,32 @@ def test_staged_kernel_large_hop(gpu):
             mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw)), f"hop {hop} clip {i}")
 
 
+def test_preemphasis_on_the_staged_kernel(gpu):
+    """Pre-emphasis (the build's optional y[n] - a y[n-1]) is applied while the staged kernel stages its
+    samples: same result as the generic kernel (which filters on load) and as the oracle, incl. clip
+    starts inside and at the edge of a tile and several clips per launch."""
+    kw, _, _ = load_golden("c1_am")
+    kw = {**kw, "preemph": 0.97}
+    plan = _plan(kw)
+    assert plan.kernel_path == "radix16-w16s"
+    for n in (4, 512, 10240, 16000, 40964):
+        clips = np.stack([O.synth_clip(80 + n + i, n, 16000, k) for i, k in enumerate(["am", "noise", "impulse"])])
+        d = _dev(clips, gpu)
+        got = plan.mfcc(d).cpu().numpy()
+        P = plan.stft_power(d).cpu().numpy()
+        with _variant(plan, "generic"):
+            gen = plan.mfcc(d).cpu().numpy()
+            Pg = plan.stft_power(d).cpu().numpy()
+        np.testing.assert_allclose(P, Pg, rtol=2e-4, atol=1e-5 * max(Pg.max(), 1e-30))
+        for i in range(clips.shape[0]):
+            want = O.mfcc(clips[i], O.OracleConfig(**kw))
+            mfcc_close(got[i], want, f"staged preemph n={n} clip {i}")
+            mfcc_close(gen[i], want, f"generic preemph n={n} clip {i}")
+    # unaligned input: no staged kernel -> generic
+    odd = _dev(np.stack([O.synth_clip(3, 16002, 16000, "am")]), gpu)
+    mfcc_close(plan.mfcc(odd)[0].cpu().numpy(), O.mfcc(odd[0].cpu().numpy(), O.OracleConfig(**kw)), "preemph n%4 != 0")
+
+
 def test_kernel_variants_selected(gpu):
     kw, _, _ = load_golden("c1_am")
     assert _plan(kw).kernel_path == "radix16-w16s"
