@@ -130,7 +130,7 @@ __device__ __forceinline__ float load_sample(const float* __restrict__ a, int64_
                                              float pre) {
   if (i < 0 || i >= n) return 0.0f;
   float v = a[i];
-  if (pre != 0.0f && i > 0) v -= pre * a[i - 1];
+  if (pre != 0.0f && i > 0) v -= __fmul_rn(pre, a[i - 1]);   // rounded product, then subtract: no fma
   return v;
 }
 
@@ -674,7 +674,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   // wave-per-frame-group kernel (n_fft = 512*R, R = 1, 2, 4): even hop, no pre-emphasis, and the mel
   // sweep must advance by at most one filter between consecutive bins of a lane's 16-bin slice
   if ((cfg->n_fft == 512 || cfg->n_fft == 1024 || cfg->n_fft == 2048) && (cfg->hop_length % 2) == 0 &&
-      cfg->preemph == 0.0f && cfg->n_mels <= MM_WPF_MAXMEL) {
+      cfg->n_mels <= MM_WPF_MAXMEL) {
     const int R = cfg->n_fft / 512, L = 16 * R, NC = 256 * R;
     mm::MelSweep sw2;
     if (mm::build_mel_sweep(*cfg, mel.data(), 1, &sw2)) {
@@ -739,11 +739,14 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       p->wpf_waves = 12;
       while (p->wpf_waves > 4 && (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes > MM_LM_LDS_MAX) p->wpf_waves -= 4;
       p->wpf_lds_bytes = (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes;
-      const void* kfn[6] = {(const void*)logmel_wpf_kernel<1, 0>, (const void*)logmel_wpf_kernel<1, 1>,
-                            (const void*)logmel_wpf_kernel<2, 0>, (const void*)logmel_wpf_kernel<2, 1>,
-                            (const void*)logmel_wpf_kernel<4, 0>, (const void*)logmel_wpf_kernel<4, 1>};
+      const void* kfn[12] = {(const void*)logmel_wpf_kernel<1, 0, false>, (const void*)logmel_wpf_kernel<1, 1, false>,
+                             (const void*)logmel_wpf_kernel<2, 0, false>, (const void*)logmel_wpf_kernel<2, 1, false>,
+                             (const void*)logmel_wpf_kernel<4, 0, false>, (const void*)logmel_wpf_kernel<4, 1, false>,
+                             (const void*)logmel_wpf_kernel<1, 0, true>, (const void*)logmel_wpf_kernel<1, 1, true>,
+                             (const void*)logmel_wpf_kernel<2, 0, true>, (const void*)logmel_wpf_kernel<2, 1, true>,
+                             (const void*)logmel_wpf_kernel<4, 0, true>, (const void*)logmel_wpf_kernel<4, 1, true>};
       bool attr_ok = p->wpf_lds_bytes <= MM_LM_LDS_MAX;
-      for (int i = 0; i < 6 && attr_ok; ++i)
+      for (int i = 0; i < 12 && attr_ok; ++i)
         attr_ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
       if (ok && attr_ok && upload(&p->d_k2_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
           upload(&p->d_k2_mel_lane, ml.data(), ml.size() * 4) == MM_OK &&
@@ -845,7 +848,10 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     if (grid > p->num_cus) grid = p->num_cus;
     const dim3 blk(64 * p->wpf_waves);
     const size_t lds = p->wpf_lds_bytes;
-#define MM_WPF_LAUNCH(RR, MM) hipLaunchKernelGGL((logmel_wpf_kernel<RR, MM>), dim3((unsigned)grid), blk, lds, st, q)
+    q.preemph = p->cfg.preemph;
+    const bool pre = p->cfg.preemph != 0.0f;
+#define MM_WPF_LAUNCH(RR, MM) do { if (pre) hipLaunchKernelGGL((logmel_wpf_kernel<RR, MM, true>), dim3((unsigned)grid), blk, lds, st, q); \
+                                   else hipLaunchKernelGGL((logmel_wpf_kernel<RR, MM, false>), dim3((unsigned)grid), blk, lds, st, q); } while (0)
     if (R == 1) { if (mode == 0) MM_WPF_LAUNCH(1, 0); else MM_WPF_LAUNCH(1, 1); }
     else if (R == 2) { if (mode == 0) MM_WPF_LAUNCH(2, 0); else MM_WPF_LAUNCH(2, 1); }
     else { if (mode == 0) MM_WPF_LAUNCH(4, 0); else MM_WPF_LAUNCH(4, 1); }

@@ -130,6 +130,17 @@ def test_preemphasis_on_the_staged_kernel(gpu):
     # unaligned input: no staged kernel -> generic
     odd = _dev(np.stack([O.synth_clip(3, 16002, 16000, "am")]), gpu)
     mfcc_close(plan.mfcc(odd)[0].cpu().numpy(), O.mfcc(odd[0].cpu().numpy(), O.OracleConfig(**kw)), "preemph n%4 != 0")
+    # n_fft 2048 / 1024 and n_fft 512 on the wave-per-frame kernel: it filters on its frame loads
+    for name, variant in (("c4_am", "wpf"), ("odd_22k", "wpf"), ("c1_am", "wpf")):
+        kw2 = {**load_golden(name)[0], "preemph": 0.95}
+        plan2 = _plan(kw2)
+        with _variant(plan2, variant):
+            assert plan2.kernel_path == "radix16-wpf"
+            for n in (2, 1023, 4801, 24001, 30000):
+                clips = np.stack([O.synth_clip(500 + n + i, n, kw2["sr"], k) for i, k in enumerate(["am", "noise"])])
+                got = plan2.mfcc(_dev(clips, gpu)).cpu().numpy()
+                for i in range(2):
+                    mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw2)), f"wpf preemph {name} n={n} clip {i}")
 
 
 def test_kernel_variants_selected(gpu):
