@@ -594,11 +594,11 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
       p->num_cus = prop.multiProcessorCount;
   }
-  // register radix-16 path: n_fft 512, even hop (8-byte frame loads); with pre-emphasis only the
-  // staged-sample kernel applies (it filters while staging), other calls then use the generic path
+  // register radix-16 path: n_fft 512; the 8-wave and the direct-load kernel need an even hop (8-byte
+  // frame loads) and have no pre-emphasis: with an odd hop or pre-emphasis only the staged-sample
+  // kernel applies (launch_stft sends the calls it cannot take to the generic kernel)
   mm::MelSweep sw;
-  if (cfg->n_fft == 512 && (cfg->hop_length % 2) == 0 &&
-      mm::build_mel_sweep(*cfg, mel.data(), 8, &sw)) {
+  if (cfg->n_fft == 512 && mm::build_mel_sweep(*cfg, mel.data(), 8, &sw)) {
     mm::MelRuns runs;
     mm::build_mel_runs(*cfg, sw, 8, &runs);
     std::vector<float> tab(runs.hdr.size() + runs.grp.size());
@@ -660,18 +660,23 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         const int span = 63 * cfg->hop_length + 512;
         const int nr = span <= 3 * 4096 ? 3 : (span <= 4 * 4096 ? 4 : 0);
         const size_t lds = nr ? (size_t)(nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tab16.size() * 4 : 0;
-        const void* kfn[8] = {(const void*)logmel512s_kernel<0, 3, false>, (const void*)logmel512s_kernel<1, 3, false>,
-                              (const void*)logmel512s_kernel<0, 4, false>, (const void*)logmel512s_kernel<1, 4, false>,
-                              (const void*)logmel512s_kernel<0, 3, true>, (const void*)logmel512s_kernel<1, 3, true>,
-                              (const void*)logmel512s_kernel<0, 4, true>, (const void*)logmel512s_kernel<1, 4, true>};
+        const void* kfn[16] = {
+            (const void*)logmel512s_kernel<0, 3, false, false>, (const void*)logmel512s_kernel<1, 3, false, false>,
+            (const void*)logmel512s_kernel<0, 4, false, false>, (const void*)logmel512s_kernel<1, 4, false, false>,
+            (const void*)logmel512s_kernel<0, 3, true, false>, (const void*)logmel512s_kernel<1, 3, true, false>,
+            (const void*)logmel512s_kernel<0, 4, true, false>, (const void*)logmel512s_kernel<1, 4, true, false>,
+            (const void*)logmel512s_kernel<0, 3, false, true>, (const void*)logmel512s_kernel<1, 3, false, true>,
+            (const void*)logmel512s_kernel<0, 4, false, true>, (const void*)logmel512s_kernel<1, 4, false, true>,
+            (const void*)logmel512s_kernel<0, 3, true, true>, (const void*)logmel512s_kernel<1, 3, true, true>,
+            (const void*)logmel512s_kernel<0, 4, true, true>, (const void*)logmel512s_kernel<1, 4, true, true>};
         bool ok = nr && lds <= MM_LM_LDS_MAX;
-        for (int i = 0; i < 8 && ok; ++i)
+        for (int i = 0; i < 16 && ok; ++i)
           ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
         if (ok) { p->s16_nr = nr; p->s16_lds_bytes = lds; }
       }
     }
   }
-  // wave-per-frame-group kernel (n_fft = 512*R, R = 1, 2, 4): even hop, no pre-emphasis, and the mel
+  // wave-per-frame-group kernel (n_fft = 512*R, R = 1, 2, 4): even hop, and the mel
   // sweep must advance by at most one filter between consecutive bins of a lane's 16-bin slice
   if ((cfg->n_fft == 512 || cfg->n_fft == 1024 || cfg->n_fft == 2048) && (cfg->hop_length % 2) == 0 &&
       cfg->n_mels <= MM_WPF_MAXMEL) {
@@ -801,11 +806,11 @@ int mm_plan_kernel_path(const mm_plan* p) {
   if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1)) return 3;
   if (p->path == 1 && p->w16_ok) {
     const int mp = dev_env("MM_PATH");
-    if (p->cfg.preemph != 0.0f) return (p->s16_nr && mp != 1 && mp != 2) ? 4 : 0;
+    if (p->cfg.preemph != 0.0f || (p->cfg.hop_length & 1)) return (p->s16_nr && mp != 1 && mp != 2) ? 4 : 0;
     if (mp == 1) return 1;
     return (p->s16_nr && mp != 2) ? 4 : 2;
   }
-  if (p->cfg.preemph != 0.0f) return 0;
+  if (p->cfg.preemph != 0.0f || (p->cfg.hop_length & 1)) return 0;
   return p->path;
 }
 
@@ -863,7 +868,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
   const bool staged_ok = p->s16_nr && p->w16_ok && (stride % 4) == 0 && (n_samples % 4) == 0 && n_samples >= 4 &&
                          (((uintptr_t)d_audio) & 15) == 0 && dev_env("MM_PATH") != 2 && dev_env("MM_PATH") != 1;
   if (p->path == 1 && !p->force_generic && (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 &&
-      n_samples >= 2 && (p->cfg.preemph == 0.0f || staged_ok)) {
+      n_samples >= 2 && ((p->cfg.preemph == 0.0f && (p->cfg.hop_length % 2) == 0) || staged_ok)) {
     Logmel512Params q;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
     q.n_frames = mm_num_frames(&p->cfg, n_samples);
@@ -883,15 +888,17 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
       if (staged_ok) {
         q.preemph = p->cfg.preemph;
         const bool pre = p->cfg.preemph != 0.0f;
-#define MM_S16_LAUNCH(MM, NN, PP) hipLaunchKernelGGL((logmel512s_kernel<MM, NN, PP>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q)
-        if (p->s16_nr == 3) {
-          if (mode == 0) { if (pre) MM_S16_LAUNCH(0, 3, true); else MM_S16_LAUNCH(0, 3, false); }
-          else { if (pre) MM_S16_LAUNCH(1, 3, true); else MM_S16_LAUNCH(1, 3, false); }
-        } else {
-          if (mode == 0) { if (pre) MM_S16_LAUNCH(0, 4, true); else MM_S16_LAUNCH(0, 4, false); }
-          else { if (pre) MM_S16_LAUNCH(1, 4, true); else MM_S16_LAUNCH(1, 4, false); }
-        }
-#undef MM_S16_LAUNCH
+#define MM_S16_LAUNCH4(MM, NN)                                                                                     \
+  do {                                                                                                             \
+    if (pre && odd) hipLaunchKernelGGL((logmel512s_kernel<MM, NN, true, true>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);        \
+    else if (pre) hipLaunchKernelGGL((logmel512s_kernel<MM, NN, true, false>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);       \
+    else if (odd) hipLaunchKernelGGL((logmel512s_kernel<MM, NN, false, true>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);       \
+    else hipLaunchKernelGGL((logmel512s_kernel<MM, NN, false, false>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);               \
+  } while (0)
+        const bool odd = p->cfg.hop_length & 1;
+        if (p->s16_nr == 3) { if (mode == 0) MM_S16_LAUNCH4(0, 3); else MM_S16_LAUNCH4(1, 3); }
+        else { if (mode == 0) MM_S16_LAUNCH4(0, 4); else MM_S16_LAUNCH4(1, 4); }
+#undef MM_S16_LAUNCH4
         HIP_TRY(hipGetLastError());
         return MM_OK;
       }

@@ -143,6 +143,22 @@ def test_preemphasis_on_the_staged_kernel(gpu):
                     mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw2)), f"wpf preemph {name} n={n} clip {i}")
 
 
+def test_odd_hop_on_the_staged_kernel(gpu):
+    """An odd hop puts odd frames at 4-byte aligned samples only: the staged kernel then reads its
+    samples from LDS as two b32 instead of one b64; the other n_fft 512 kernels need an even hop."""
+    for hop, pre in ((161, 0.0), (77, 0.0), (11, 0.97), (251, 0.0)):
+        kw = dict(sr=16000, n_fft=512, win_length=400, hop_length=hop, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0,
+                  preemph=pre)
+        plan = _plan(kw)
+        assert plan.kernel_path == "radix16-w16s"
+        clips = np.stack([O.synth_clip(600 + hop + i, 20000, 16000, k) for i, k in enumerate(["am", "noise", "am"])])
+        got = plan.mfcc(_dev(clips, gpu)).cpu().numpy()
+        for i in range(3):
+            mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw)), f"odd hop {hop} clip {i}")
+        with _variant(plan, "w16"):
+            assert plan.kernel_path == "generic"
+
+
 def test_kernel_variants_selected(gpu):
     kw, _, _ = load_golden("c1_am")
     assert _plan(kw).kernel_path == "radix16-w16s"
@@ -153,7 +169,8 @@ def test_kernel_variants_selected(gpu):
     assert _plan({**kw, "n_mels": 256}).kernel_path == "radix16-w8"      # mel table too big for w16
     assert _plan(load_golden("c4_am")[0]).kernel_path == "radix16-wpf"     # n_fft 2048: wave-per-frame kernel
     assert _plan(load_golden("odd_22k")[0]).kernel_path == "radix16-wpf"   # n_fft 1024, even hop
-    assert _plan(load_golden("ragged_preemph")[0]).kernel_path == "generic"  # odd hop + pre-emphasis
+    assert _plan(load_golden("ragged_preemph")[0]).kernel_path == "radix16-w16s"  # odd hop + pre-emphasis: staged kernel only
+    assert _plan({**load_golden("c4_am")[0], "hop_length": 481}).kernel_path == "generic"   # n_fft 2048 needs an even hop
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
