@@ -660,18 +660,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         const int span = 63 * cfg->hop_length + 512;
         const int nr = span <= 3 * 4096 ? 3 : (span <= 4 * 4096 ? 4 : 0);
         const size_t lds = nr ? (size_t)(nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tab16.size() * 4 : 0;
-        const void* kfn[16] = {
-            (const void*)logmel512s_kernel<0, 3, false, false>, (const void*)logmel512s_kernel<1, 3, false, false>,
-            (const void*)logmel512s_kernel<0, 4, false, false>, (const void*)logmel512s_kernel<1, 4, false, false>,
-            (const void*)logmel512s_kernel<0, 3, true, false>, (const void*)logmel512s_kernel<1, 3, true, false>,
-            (const void*)logmel512s_kernel<0, 4, true, false>, (const void*)logmel512s_kernel<1, 4, true, false>,
-            (const void*)logmel512s_kernel<0, 3, false, true>, (const void*)logmel512s_kernel<1, 3, false, true>,
-            (const void*)logmel512s_kernel<0, 4, false, true>, (const void*)logmel512s_kernel<1, 4, false, true>,
-            (const void*)logmel512s_kernel<0, 3, true, true>, (const void*)logmel512s_kernel<1, 3, true, true>,
-            (const void*)logmel512s_kernel<0, 4, true, true>, (const void*)logmel512s_kernel<1, 4, true, true>};
-        bool ok = nr && lds <= MM_LM_LDS_MAX;
-        for (int i = 0; i < 16 && ok; ++i)
-          ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
+        const bool ok = nr && lds <= MM_LM_LDS_MAX && set_s16_attr(MM_LM_LDS_MAX);
         if (ok) { p->s16_nr = nr; p->s16_lds_bytes = lds; }
       }
     }
@@ -865,10 +854,10 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     return MM_OK;
   }
   // pre-emphasis exists only in the staged-sample kernel (applied while staging)
-  const bool staged_ok = p->s16_nr && p->w16_ok && (stride % 4) == 0 && (n_samples % 4) == 0 && n_samples >= 4 &&
-                         (((uintptr_t)d_audio) & 15) == 0 && dev_env("MM_PATH") != 2 && dev_env("MM_PATH") != 1;
-  if (p->path == 1 && !p->force_generic && (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 &&
-      n_samples >= 2 && ((p->cfg.preemph == 0.0f && (p->cfg.hop_length % 2) == 0) || staged_ok)) {
+  const bool staged_ok = p->s16_nr && p->w16_ok && n_samples >= 4 && dev_env("MM_PATH") != 2 && dev_env("MM_PATH") != 1;
+  const bool direct_ok = (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2 &&
+                         p->cfg.preemph == 0.0f && (p->cfg.hop_length % 2) == 0;      // 8-wave / direct-load 16-wave kernels
+  if (p->path == 1 && !p->force_generic && (direct_ok || staged_ok)) {
     Logmel512Params q;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
     q.n_frames = mm_num_frames(&p->cfg, n_samples);
@@ -888,17 +877,9 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
       if (staged_ok) {
         q.preemph = p->cfg.preemph;
         const bool pre = p->cfg.preemph != 0.0f;
-#define MM_S16_LAUNCH4(MM, NN)                                                                                     \
-  do {                                                                                                             \
-    if (pre && odd) hipLaunchKernelGGL((logmel512s_kernel<MM, NN, true, true>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);        \
-    else if (pre) hipLaunchKernelGGL((logmel512s_kernel<MM, NN, true, false>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);       \
-    else if (odd) hipLaunchKernelGGL((logmel512s_kernel<MM, NN, false, true>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);       \
-    else hipLaunchKernelGGL((logmel512s_kernel<MM, NN, false, false>), dim3((unsigned)grid), dim3(1024), p->s16_lds_bytes, st, q);               \
-  } while (0)
         const bool odd = p->cfg.hop_length & 1;
-        if (p->s16_nr == 3) { if (mode == 0) MM_S16_LAUNCH4(0, 3); else MM_S16_LAUNCH4(1, 3); }
-        else { if (mode == 0) MM_S16_LAUNCH4(0, 4); else MM_S16_LAUNCH4(1, 4); }
-#undef MM_S16_LAUNCH4
+        const bool unal = (stride % 4) != 0 || (n_samples % 4) != 0 || (((uintptr_t)d_audio) & 15) != 0;
+        launch_s16(mode, p->s16_nr, pre, odd, unal, dim3((unsigned)grid), p->s16_lds_bytes, st, q);
         HIP_TRY(hipGetLastError());
         return MM_OK;
       }

@@ -94,6 +94,30 @@ def test_staged_kernel_lengths(n, gpu):
         mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw)), f"w16s n={n} clip {i}")
 
 
+@pytest.mark.parametrize("n", [5, 6, 7, 161, 1022, 10241, 16001, 16002, 16003, 40963])
+def test_staged_kernel_unaligned(n, gpu):
+    """Lengths that are not multiples of 4, odd row pitches and rows that start off a 16-byte boundary
+    run on the UNAL instantiation of the staged kernel (4-byte aligned 16-byte loads, the group that
+    straddles the clip end re-aligned): == oracle, and bit-identical to the direct-load kernel where
+    that one applies (even pitch, 8-byte aligned rows)."""
+    import torch
+    kw, _, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    clips = np.stack([O.synth_clip(900 + n + i, n, 16000, k) for i, k in enumerate(["am", "noise", "am"])])
+    want = [O.mfcc(c, O.OracleConfig(**kw)) for c in clips]
+    for pad, lead in ((0, 0), (1, 0), (2, 2), (3, 1), (6, 3)):
+        big = torch.zeros((3, lead + n + pad), dtype=torch.float32, device=gpu)
+        big[:, lead:lead + n] = _dev(clips, gpu)
+        view = big[:, lead:lead + n]
+        got = plan.mfcc(view).cpu().numpy()
+        for i in range(3):
+            mfcc_close(got[i], want[i], f"unaligned n={n} pad={pad} lead={lead} clip {i}")
+        if (lead + n + pad) % 2 == 0 and lead % 2 == 0 and n >= 2:
+            with _variant(plan, "w16"):
+                ref = plan.mfcc(view).cpu().numpy()
+            np.testing.assert_array_equal(got, ref)
+
+
 def test_staged_kernel_large_hop(gpu):
     """hop 240 needs four 16-byte groups per thread (NR = 4); hop 200 with n_fft 512 / win 512."""
     for hop, win in ((240, 480), (200, 512), (184, 400), (188, 400)):
