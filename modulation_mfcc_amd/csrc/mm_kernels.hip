@@ -823,8 +823,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
                        hipStream_t st, bool frame_major = false, bool* is_fm = nullptr) {
   if (is_fm) *is_fm = false;
   const bool force_wpf = dev_env("MM_PATH") == 3;
-  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1) && !p->force_generic &&
-      (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2) {
+  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1) && !p->force_generic && n_samples >= 2) {
     WpfParams q;
     const int R = p->wpf_r, F = 4 / R;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;

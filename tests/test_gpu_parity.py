@@ -240,6 +240,25 @@ def test_nfft2048_kernel_vs_generic_and_oracle(n, gpu):
     np.testing.assert_allclose(mx.cpu().numpy(), mxg.cpu().numpy(), rtol=0, atol=2e-3)
 
 
+def test_wpf_unaligned_rows(gpu):
+    """n_fft 2048 / 1024 on odd row pitches and rows starting off an 8-byte boundary (the frame loads are
+    8-byte loads at 4-byte aligned addresses)."""
+    import torch
+    for name in ("c4_am", "odd_22k"):
+        kw = load_golden(name)[0]
+        plan = _plan(kw)
+        assert plan.kernel_path == "radix16-wpf"
+        for n in (4801, 24000, 24003):
+            clips = np.stack([O.synth_clip(70 + n + i, n, kw["sr"], k) for i, k in enumerate(["am", "noise"])])
+            want = [O.mfcc(c, O.OracleConfig(**kw)) for c in clips]
+            for pad, lead in ((0, 0), (1, 0), (3, 1), (2, 3)):
+                big = torch.zeros((2, lead + n + pad), dtype=torch.float32, device=gpu)
+                big[:, lead:lead + n] = _dev(clips, gpu)
+                got = plan.mfcc(big[:, lead:lead + n]).cpu().numpy()
+                for i in range(2):
+                    mfcc_close(got[i], want[i], f"{name} n={n} pad={pad} lead={lead} clip {i}")
+
+
 def test_nfft2048_batch_determinism(gpu):
     import torch
     kw, _, _ = load_golden("c4_am")
