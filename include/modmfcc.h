@@ -115,8 +115,7 @@ int mm_plan_config(const mm_plan* plan, mm_config* out);
 /* which fused STFT kernel mm_mfcc_f32 / mm_logmel_f32 / mm_stft_power_f32 use: 0 = generic LDS
  * radix-2, 1 = register radix-16, 8 waves per workgroup, 2 = register radix-16, 16 waves (n_fft 512,
  * even hop, no pre-emphasis -- with an odd hop or pre-emphasis only variant 4 applies; 2 needs the mel run table to fit beside the 154 KB of tiles in LDS),
- * 3 = register radix-16 wave-per-frame-group kernel (n_fft 1024 / 2048, or n_fft 512 with MM_PATH=3;
- * even hop, no pre-emphasis), 4 = variant 2 with the tile's samples staged through LDS (hop <= 252,
+ * 3 = register radix-16 wave-per-frame-group kernel (n_fft 1024 / 2048, or n_fft 512 with MM_PATH=3), 4 = variant 2 with the tile's samples staged through LDS (hop <= 252,
  * n_samples >= 4; any hop parity, row alignment and length, optional pre-emphasis).  MM_PATH=1 / 2 in the environment pin variants 1 / 2 (development). */
 int mm_plan_kernel_path(const mm_plan* plan);
 /* force the generic kernels (debug / cross-check); returns previous value */

@@ -665,10 +665,9 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       }
     }
   }
-  // wave-per-frame-group kernel (n_fft = 512*R, R = 1, 2, 4): even hop, and the mel
+  // wave-per-frame-group kernel (n_fft = 512*R, R = 1, 2, 4): the mel
   // sweep must advance by at most one filter between consecutive bins of a lane's 16-bin slice
-  if ((cfg->n_fft == 512 || cfg->n_fft == 1024 || cfg->n_fft == 2048) && (cfg->hop_length % 2) == 0 &&
-      cfg->n_mels <= MM_WPF_MAXMEL) {
+  if ((cfg->n_fft == 512 || cfg->n_fft == 1024 || cfg->n_fft == 2048) && cfg->n_mels <= MM_WPF_MAXMEL) {
     const int R = cfg->n_fft / 512, L = 16 * R, NC = 256 * R;
     mm::MelSweep sw2;
     if (mm::build_mel_sweep(*cfg, mel.data(), 1, &sw2)) {

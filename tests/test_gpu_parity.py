@@ -194,7 +194,7 @@ def test_kernel_variants_selected(gpu):
     assert _plan(load_golden("c4_am")[0]).kernel_path == "radix16-wpf"     # n_fft 2048: wave-per-frame kernel
     assert _plan(load_golden("odd_22k")[0]).kernel_path == "radix16-wpf"   # n_fft 1024, even hop
     assert _plan(load_golden("ragged_preemph")[0]).kernel_path == "radix16-w16s"  # odd hop + pre-emphasis: staged kernel only
-    assert _plan({**load_golden("c4_am")[0], "hop_length": 481}).kernel_path == "generic"   # n_fft 2048 needs an even hop
+    assert _plan({**load_golden("c4_am")[0], "hop_length": 481}).kernel_path == "radix16-wpf"   # any hop parity
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -257,6 +257,19 @@ def test_wpf_unaligned_rows(gpu):
                 got = plan.mfcc(big[:, lead:lead + n]).cpu().numpy()
                 for i in range(2):
                     mfcc_close(got[i], want[i], f"{name} n={n} pad={pad} lead={lead} clip {i}")
+
+
+def test_wpf_odd_hop(gpu):
+    for name, hop in (("c4_am", 481), ("odd_22k", 221), ("c1_am", 161)):
+        kw = {**load_golden(name)[0], "hop_length": hop}
+        plan = _plan(kw)
+        with _variant(plan, "wpf"):
+            assert plan.kernel_path == "radix16-wpf"
+            for n in (2, 3, 4800, 24001, 30000):
+                clips = np.stack([O.synth_clip(170 + n + i, n, kw["sr"], k) for i, k in enumerate(["am", "noise"])])
+                got = plan.mfcc(_dev(clips, gpu)).cpu().numpy()
+                for i in range(2):
+                    mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw)), f"wpf odd hop {name} n={n} clip {i}")
 
 
 def test_nfft2048_batch_determinism(gpu):
