@@ -822,7 +822,14 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
                        hipStream_t st, bool frame_major = false, bool* is_fm = nullptr) {
   if (is_fm) *is_fm = false;
   const bool force_wpf = dev_env("MM_PATH") == 3;
-  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1) && !p->force_generic && n_samples >= 2) {
+  // which n_fft = 512 tile kernels can take this call: the staged one (pre-emphasis, any hop parity,
+  // alignment and length, hop <= 252) or the 8-wave / direct-load 16-wave kernels; what they cannot
+  // take goes to the wave-per-frame kernel before the generic one
+  const bool staged_ok = p->s16_nr && p->w16_ok && n_samples >= 4 && dev_env("MM_PATH") != 2 && dev_env("MM_PATH") != 1;
+  const bool direct_ok = (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2 &&
+                         p->cfg.preemph == 0.0f && (p->cfg.hop_length % 2) == 0;
+  const bool tile_ok = p->path == 1 && (direct_ok || staged_ok);
+  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || !tile_ok) && !p->force_generic && n_samples >= 2) {
     WpfParams q;
     const int R = p->wpf_r, F = 4 / R;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
@@ -851,11 +858,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     HIP_TRY(hipGetLastError());
     return MM_OK;
   }
-  // pre-emphasis exists only in the staged-sample kernel (applied while staging)
-  const bool staged_ok = p->s16_nr && p->w16_ok && n_samples >= 4 && dev_env("MM_PATH") != 2 && dev_env("MM_PATH") != 1;
-  const bool direct_ok = (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2 &&
-                         p->cfg.preemph == 0.0f && (p->cfg.hop_length % 2) == 0;      // 8-wave / direct-load 16-wave kernels
-  if (p->path == 1 && !p->force_generic && (direct_ok || staged_ok)) {
+  if (tile_ok && !p->force_generic) {
     Logmel512Params q;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
     q.n_frames = mm_num_frames(&p->cfg, n_samples);

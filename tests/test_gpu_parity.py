@@ -259,6 +259,28 @@ def test_wpf_unaligned_rows(gpu):
                     mfcc_close(got[i], want[i], f"{name} n={n} pad={pad} lead={lead} clip {i}")
 
 
+def test_nfft512_calls_beyond_the_tile_kernels(gpu):
+    """n_fft 512 with a hop too large for the staged kernel's LDS sample buffer (> 252): even hop and
+    aligned rows run on the direct-load kernel, everything else on the wave-per-frame kernel (not the
+    generic one)."""
+    for hop, n in ((300, 30000), (301, 30000), (300, 30001), (257, 12345)):
+        kw = dict(sr=16000, n_fft=512, win_length=400, hop_length=hop, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0)
+        plan = _plan(kw)
+        clips = np.stack([O.synth_clip(33 + hop + i, n, 16000, k) for i, k in enumerate(["am", "noise"])])
+        d = _dev(clips, gpu)
+        got = plan.mfcc(d).cpu().numpy()
+        with _variant(plan, "generic"):
+            gen = plan.mfcc(d).cpu().numpy()
+        for i in range(2):
+            want = O.mfcc(clips[i], O.OracleConfig(**kw))
+            mfcc_close(got[i], want, f"hop {hop} n={n} clip {i}")
+            mfcc_close(gen[i], want, f"generic hop {hop} n={n} clip {i}")
+        plan.timing_enable(True)
+        plan.mfcc(d)
+        plan.timing_enable(False)
+        assert "logmel" in plan.timing_read()
+
+
 def test_wpf_odd_hop(gpu):
     for name, hop in (("c4_am", 481), ("odd_22k", 221), ("c1_am", 161)):
         kw = {**load_golden(name)[0], "hop_length": hop}
