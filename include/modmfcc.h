@@ -116,7 +116,9 @@ int mm_plan_config(const mm_plan* plan, mm_config* out);
  * radix-2, 1 = register radix-16, 8 waves per workgroup, 2 = register radix-16, 16 waves (n_fft 512,
  * even hop, no pre-emphasis -- with an odd hop or pre-emphasis only variant 4 applies; 2 needs the mel run table to fit beside the 154 KB of tiles in LDS),
  * 3 = register radix-16 wave-per-frame-group kernel (n_fft 1024 / 2048, or n_fft 512 with MM_PATH=3), 4 = variant 2 with the tile's samples staged through LDS (hop <= 252,
- * n_samples >= 4; any hop parity, row alignment and length, optional pre-emphasis).  MM_PATH=1 / 2 in the environment pin variants 1 / 2 (development). */
+ * n_samples >= 4; any hop parity, row alignment and length, optional pre-emphasis).  n_fft 64 / 128 /
+ * 256 plans use the n_fft 512 variants too (frames zero-padded to 512 points: same power at every
+ * (512/n_fft)-th bin).  MM_PATH=1 / 2 in the environment pin variants 1 / 2 (development). */
 int mm_plan_kernel_path(const mm_plan* plan);
 /* force the generic kernels (debug / cross-check); returns previous value */
 int mm_plan_force_generic(mm_plan* plan, int on);

@@ -301,6 +301,8 @@ struct mm_plan {
   int s16_nr;                      // staged-sample variant: 16-byte groups per thread and tile (0: not usable)
   size_t s16_lds_bytes;
 
+  float* d_window_e;                       // n_fft < 512 embedded in the 512-point kernels: window centred in 512
+  int embed;                               // 512 / n_fft for such plans, else 1
   float *d_k2_lane_tab, *d_k2_mel_lane;   // wave-per-frame-group kernel (n_fft 512 / 1024 / 2048)
   float* d_rf2k_lane_tab;                 // rfft_wpf_kernel<4> (stage-isolated rFFT, n = 2048)
   int rf2k_ok;
@@ -559,7 +561,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_sw_tab = nullptr; p->d_sw_part = nullptr;
   p->d_w16_tab = p->d_lane_tab = nullptr; p->d_w16_part = nullptr; p->w16_ok = 0; p->s16_nr = 0; p->s16_lds_bytes = 0;
 
-  p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0;
+  p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
@@ -594,13 +596,36 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
       p->num_cus = prop.multiProcessorCount;
   }
+  // n_fft 64 / 128 / 256 ride on the n_fft = 512 tile kernels: a frame zero-padded to 512 points around
+  // its centre has X512[E*k] = (-1)^k X_nfft[k] (E = 512 / n_fft), i.e. the same power at every E-th
+  // bin.  So the window is the Hann(win_length) centred in 512 and the mel weights sit at the bins E*k
+  // (zero elsewhere); frame count, centre padding and everything downstream are unchanged.  (The
+  // stage output mm_stft_power_f32 keeps the generic kernel: its rows have n_fft/2 + 1 bins.)
+  mm_config cfg_e = *cfg;
+  std::vector<float> win_e, mel_e;
+  const mm_config* ce = cfg;
+  const float* melp = mel.data();
+  const float* winp = win.data();
+  p->embed = 1;
+  if (cfg->n_fft == 256 || cfg->n_fft == 128 || cfg->n_fft == 64) {
+    const int E = 512 / cfg->n_fft;
+    cfg_e.n_fft = 512;
+    win_e.resize(512);
+    mm::build_window(cfg_e, win_e.data());
+    mel_e.assign((size_t)cfg->n_mels * 257, 0.0f);
+    for (int m = 0; m < cfg->n_mels; ++m)
+      for (int k = 0; k < p->n_bins; ++k) mel_e[(size_t)m * 257 + (size_t)E * k] = mel[(size_t)m * p->n_bins + k];
+    if (upload(&p->d_window_e, win_e.data(), win_e.size() * 4) == MM_OK) {
+      ce = &cfg_e; melp = mel_e.data(); winp = win_e.data(); p->embed = E;
+    }
+  }
   // register radix-16 path: n_fft 512; the 8-wave and the direct-load kernel need an even hop (8-byte
   // frame loads) and have no pre-emphasis: with an odd hop or pre-emphasis only the staged-sample
   // kernel applies (launch_stft sends the calls it cannot take to the generic kernel)
   mm::MelSweep sw;
-  if (cfg->n_fft == 512 && mm::build_mel_sweep(*cfg, mel.data(), 8, &sw)) {
+  if (ce->n_fft == 512 && mm::build_mel_sweep(*ce, melp, 8, &sw)) {
     mm::MelRuns runs;
-    mm::build_mel_runs(*cfg, sw, 8, &runs);
+    mm::build_mel_runs(*ce, sw, 8, &runs);
     std::vector<float> tab(runs.hdr.size() + runs.grp.size());
     std::memcpy(tab.data(), runs.hdr.data(), runs.hdr.size() * 4);
     std::memcpy(tab.data() + runs.hdr.size(), runs.grp.data(), runs.grp.size() * 4);
@@ -622,9 +647,9 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       p->path = 1;
     // 16-wave variant (4 waves per SIMD): needs its own 16-way mel partition and lane records
     mm::MelSweep sw16;
-    if (p->path == 1 && mm::build_mel_sweep(*cfg, mel.data(), 16, &sw16)) {
+    if (p->path == 1 && mm::build_mel_sweep(*ce, melp, 16, &sw16)) {
       mm::MelRuns r16;
-      mm::build_mel_runs(*cfg, sw16, 16, &r16);
+      mm::build_mel_runs(*ce, sw16, 16, &r16);
       std::vector<float> tab16(r16.hdr.size() + r16.grp.size());
       std::memcpy(tab16.data(), r16.hdr.data(), r16.hdr.size() * 4);
       std::memcpy(tab16.data() + r16.hdr.size(), r16.grp.data(), r16.grp.size() * 4);
@@ -635,7 +660,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       std::vector<float> lt(16 * MM_W16_LT_PITCH, 0.0f);
       for (int q = 0; q < 16; ++q) {
         float* r = lt.data() + q * MM_W16_LT_PITCH;
-        for (int n1 = 0; n1 < 16; ++n1) { r[2 * n1] = win[32 * n1 + 2 * q]; r[2 * n1 + 1] = win[32 * n1 + 2 * q + 1]; }
+        for (int n1 = 0; n1 < 16; ++n1) { r[2 * n1] = winp[32 * n1 + 2 * q]; r[2 * n1 + 1] = winp[32 * n1 + 2 * q + 1]; }
         for (int k1 = 1; k1 < 16; ++k1) {
           const int idx = (q * k1) * (MM_TW_N / 256);
           r[32 + 2 * (k1 - 1)] = tw[2 * idx]; r[32 + 2 * (k1 - 1) + 1] = tw[2 * idx + 1];
@@ -774,7 +799,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_sw_tab); (void)hipFree(p->d_sw_part);
   (void)hipFree(p->d_w16_tab); (void)hipFree(p->d_lane_tab); (void)hipFree(p->d_w16_part);
 
-  (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane);
+  (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane); (void)hipFree(p->d_window_e);
   (void)hipFree(p->d_rf2k_lane_tab);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
@@ -828,7 +853,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
   const bool staged_ok = p->s16_nr && p->w16_ok && n_samples >= 4 && dev_env("MM_PATH") != 2 && dev_env("MM_PATH") != 1;
   const bool direct_ok = (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2 &&
                          p->cfg.preemph == 0.0f && (p->cfg.hop_length % 2) == 0;
-  const bool tile_ok = p->path == 1 && (direct_ok || staged_ok);
+  const bool tile_ok = p->path == 1 && (direct_ok || staged_ok) && (p->embed == 1 || mode != 0);
   if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || !tile_ok) && !p->force_generic && n_samples >= 2) {
     WpfParams q;
     const int R = p->wpf_r, F = 4 / R;
@@ -865,7 +890,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.tiles_per_clip = (q.n_frames + 63) / 64;
     q.n_tiles = batch * q.tiles_per_clip;
     q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
-    q.window = p->d_window; q.tw = p->d_tw; q.mel_tab = (const float4*)p->d_sw_tab; q.n_runs = p->sw_n_runs; q.n_tab16 = p->sw_n_tab16;
+    q.window = p->embed > 1 ? p->d_window_e : p->d_window; q.tw = p->d_tw; q.mel_tab = (const float4*)p->d_sw_tab; q.n_runs = p->sw_n_runs; q.n_tab16 = p->sw_n_tab16;
     q.wave_part = p->d_sw_part; q.out_logmel = out_logmel; q.clip_key = clip_key;
     q.out_power = out_power;
     q.dbg = dev_env("MM_DEBUG");

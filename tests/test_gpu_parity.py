@@ -259,6 +259,30 @@ def test_wpf_unaligned_rows(gpu):
                     mfcc_close(got[i], want[i], f"{name} n={n} pad={pad} lead={lead} clip {i}")
 
 
+@pytest.mark.parametrize("n_fft,win,hop,sr", [(256, 200, 80, 8000), (256, 256, 64, 8000), (128, 100, 25, 8000),
+                                                (64, 64, 16, 8000), (256, 250, 50, 10000), (256, 201, 77, 16000)])
+def test_small_nfft_on_the_512_kernels(n_fft, win, hop, sr, gpu):
+    """n_fft 64 / 128 / 256 run on the n_fft 512 tile kernels (frame zero-padded to 512 points around its
+    centre: same power at every (512/n_fft)-th bin): == oracle == generic kernel, clamp and all."""
+    kw = dict(sr=sr, n_fft=n_fft, win_length=win, hop_length=hop, n_mels=min(40, n_fft // 4), n_mfcc=13 if n_fft > 64 else 8,
+              fmin=50.0, fmax=sr / 2)
+    plan = _plan(kw)
+    assert plan.kernel_path == "radix16-w16s"
+    for n in (37, 4000, 16001):
+        clips = np.stack([O.synth_clip(11 + n + i, n, sr, k) for i, k in enumerate(["am", "noise", "quiet_tail"])])
+        d = _dev(clips, gpu)
+        got = plan.mfcc(d).cpu().numpy()
+        P = plan.stft_power(d).cpu().numpy()
+        assert P.shape[-1] == n_fft // 2 + 1
+        with _variant(plan, "generic"):
+            gen = plan.mfcc(d).cpu().numpy()
+        for i in range(3):
+            want = O.mfcc(clips[i], O.OracleConfig(**kw))
+            assert got[i].shape == want.shape
+            mfcc_close(got[i], want, f"n_fft {n_fft} n={n} clip {i}")
+            mfcc_close(gen[i], want, f"generic n_fft {n_fft} n={n} clip {i}")
+
+
 def test_nfft512_calls_beyond_the_tile_kernels(gpu):
     """n_fft 512 with a hop too large for the staged kernel's LDS sample buffer (> 252): even hop and
     aligned rows run on the direct-load kernel, everything else on the wave-per-frame kernel (not the
