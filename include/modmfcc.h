@@ -112,16 +112,22 @@ int mm_build_butter_sos(int order, double wn, double* sos /*[(order+1)/2][6]*/);
 int mm_plan_create(const mm_config* cfg, mm_plan** out);
 int mm_plan_destroy(mm_plan* plan);
 int mm_plan_config(const mm_plan* plan, mm_config* out);
-/* which fused STFT kernel mm_mfcc_f32 / mm_logmel_f32 / mm_stft_power_f32 use: 0 = generic LDS
- * radix-2, 1 = register radix-16, 8 waves per workgroup, 2 = register radix-16, 16 waves (n_fft 512,
- * even hop, no pre-emphasis -- with an odd hop or pre-emphasis only variant 4 applies; 2 needs the mel run table to fit beside the 154 KB of tiles in LDS),
- * 3 = register radix-16 wave-per-frame-group kernel (n_fft 1024 / 2048, or n_fft 512 with MM_PATH=3), 4 = variant 2 with the tile's samples staged through LDS (hop <= 252,
- * n_samples >= 4; any hop parity, row alignment and length, optional pre-emphasis).  n_fft 64 / 128 /
- * 256 plans use the n_fft 512 variants too (frames zero-padded to 512 points: same power at every
- * (512/n_fft)-th bin).  MM_PATH=1 / 2 in the environment pin variants 1 / 2 (development). */
+/* Which fused kernel a log-mel / MFCC call of this plan runs on, for a regular call (aligned rows,
+ * n_samples >= 4): 0 = generic LDS radix-2; 1 = register radix-16, 8 waves per workgroup; 2 = register
+ * radix-16, 16 waves, direct loads (n_fft 512, even hop, no pre-emphasis); 3 = register radix-16
+ * wave-per-frame-group kernel (n_fft 1024 / 2048, and what is left of n_fft 512); 4 = variant 2 with the
+ * tile's samples staged through LDS (hop <= 252; any hop parity, row alignment and length, optional
+ * pre-emphasis); 5 = 12-wave kernel with the mel contraction (and for n_mfcc <= 16 the DCT-II) on the
+ * matrix pipe, 48-frame double-buffered power tiles (n_fft 512, hop <= 170 at 40 mel: the tables must fit
+ * the 160 KB of LDS) -- opt-in (mm_plan_set_variant): measured slower than variant 4, see DESIGN.md.  n_fft 64 / 128 / 256 plans use the n_fft 512
+ * variants too (frames zero-padded to 512 points: same power at every (512/n_fft)-th bin). */
 int mm_plan_kernel_path(const mm_plan* plan);
 /* force the generic kernels (debug / cross-check); returns previous value */
 int mm_plan_force_generic(mm_plan* plan, int on);
+/* pin one of the variants above (1..5) for the calls it can take, 0 = automatic choice; returns the
+ * previous setting.  Results of all variants agree within float32 round-off (tests/test_gpu_parity.py);
+ * this is how the tests and tools/ab.sh select a kernel -- the library reads no environment variable. */
+int mm_plan_set_variant(mm_plan* plan, int variant);
 size_t mm_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_samples);
 
 /* ---- compute (device pointers, async on `stream`) ---------------------------------------

@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmodmfcc.so")
+# MODMFCC_LIB: load another build of the library (development: ablation / stamp builds made by tools/*.sh
+# go to their own files instead of overwriting the product library)
+LIB_PATH = os.environ.get("MODMFCC_LIB") or os.path.join(_HERE, "libmodmfcc.so")
 
 MM_OK = 0
 MM_ERR_INVALID_ARG = -1
@@ -72,6 +74,7 @@ PROTOTYPES = {
     "mm_plan_config": (C.c_int, [_vp, _cfgp]),
     "mm_plan_kernel_path": (C.c_int, [_vp]),
     "mm_plan_force_generic": (C.c_int, [_vp, C.c_int]),
+    "mm_plan_set_variant": (C.c_int, [_vp, C.c_int]),
     "mm_workspace_bytes": (C.c_size_t, [_vp, _i64, _i64]),
     "mm_mfcc_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, C.c_size_t, _vp]),
     "mm_logmel_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -271,12 +271,14 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_logmel16w.hip.inc"
 #include "mm_change.hip.inc"
 #include "mm_logmel16s.hip.inc"
+#include "mm_logmel12m.hip.inc"
 #include "mm_wpf.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------
 #define MM_MAX_TIMED 16384
+#define MM_MAX_SAMPLES (((int64_t)1 << 29) - 8192)
 
 struct mm_plan {
   mm_config cfg;
@@ -300,6 +302,14 @@ struct mm_plan {
   size_t w16_lds_bytes;
   int s16_nr;                      // staged-sample variant: 16-byte groups per thread and tile (0: not usable)
   size_t s16_lds_bytes;
+  // 12-wave MFMA-mel variant (mm_logmel12m.hip.inc)
+  float *d_m12_a, *d_m12_dct, *d_zeros;
+  int m12_units[MM_M12_MW * MM_M12_UMAX * 4], m12_nunits[8];
+  int m12_ok, m12_nb, m12_nstep8, m12_nr, m12_s_floats, m12_fused_dct;
+  unsigned m12_win_off, m12_tw_off, m12_a_off, m12_dct_off, m12_part_off, m12_cnt_off;
+  int m12_n_a2;
+  size_t m12_lds_bytes;
+  int variant;                     // mm_plan_set_variant: 0 = automatic
 
   float* d_window_e;                       // n_fft < 512 embedded in the 512-point kernels: window centred in 512
   int embed;                               // 512 / n_fft for such plans, else 1
@@ -319,13 +329,6 @@ struct mm_plan {
 };
 
 namespace {
-
-// development switches (tools/README.md): MM_PATH pins a fused-kernel variant, MM_DEBUG is the ablation
-// mask of the direct-load 16-wave kernel; read per call so that tests can flip them
-static int dev_env(const char* name) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : 0;
-}
 
 struct StageTimer {
   mm_plan* p;
@@ -563,6 +566,8 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
 
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
+  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0;
+  p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
     g_hip_err = "hipGetDevice failed (no GPU?)";
@@ -633,18 +638,21 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     p->sw_n_runs = (int)(runs.hdr.size() / 4);
     p->sw_n_tab16 = (int)(tab.size() / 4);
     p->lm_lds_bytes = (size_t)MM_LM_TAB_OFF + tab.size() * 4;
-    if (p->lm_lds_bytes > MM_LM_LDS_MAX) { *out = p; return MM_OK; }   // stays on the generic path
-    if ((rc = upload(&p->d_sw_tab, tab.data(), tab.size() * 4)) ||
-        (rc = upload(&p->d_sw_part, runs.part.data(), runs.part.size() * 4))) {
-      mm_plan_destroy(p);
-      return rc;
+    // (a run table that does not fit beside the 8-wave kernel's tiles leaves n_fft 512 to the
+    // wave-per-frame or the generic kernel; the set-up below this block still runs)
+    if (p->lm_lds_bytes <= MM_LM_LDS_MAX) {
+      if ((rc = upload(&p->d_sw_tab, tab.data(), tab.size() * 4)) ||
+          (rc = upload(&p->d_sw_part, runs.part.data(), runs.part.size() * 4))) {
+        mm_plan_destroy(p);
+        return rc;
+      }
+      if (hipFuncSetAttribute((const void*)logmel512_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              MM_LM_LDS_MAX) == hipSuccess &&
+          hipFuncSetAttribute((const void*)logmel512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              MM_LM_LDS_MAX) == hipSuccess)   // the attribute is per function, not per plan:
+                                                               // always the 160 KB maximum
+        p->path = 1;
     }
-    if (hipFuncSetAttribute((const void*)logmel512_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            MM_LM_LDS_MAX) == hipSuccess &&
-        hipFuncSetAttribute((const void*)logmel512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            MM_LM_LDS_MAX) == hipSuccess)   // the attribute is per function, not per plan:
-                                                             // always the 160 KB maximum
-      p->path = 1;
     // 16-wave variant (4 waves per SIMD): needs its own 16-way mel partition and lane records
     mm::MelSweep sw16;
     if (p->path == 1 && mm::build_mel_sweep(*ce, melp, 16, &sw16)) {
@@ -687,6 +695,35 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         const size_t lds = nr ? (size_t)(nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tab16.size() * 4 : 0;
         const bool ok = nr && lds <= MM_LM_LDS_MAX && set_s16_attr(MM_LM_LDS_MAX);
         if (ok) { p->s16_nr = nr; p->s16_lds_bytes = lds; }
+      }
+      // 12-wave MFMA-mel variant (mm_logmel12m.hip.inc): banded A-operand table, unit lists, LDS budget
+      if (p->w16_ok) {
+        M12Tables mt;
+        const int s_floats = (47 * cfg->hop_length + 512 + 255) & ~255;
+        const int nr = (s_floats / 256 + 15) / 16;     // 1 KiB pieces (or 4 KiB of register-staged groups) per wave
+        if (nr <= 3 && build_m12_tables(*ce, melp, dct.data(), &mt)) {
+          p->m12_nb = mt.nb; p->m12_nr = nr; p->m12_s_floats = s_floats;
+          p->m12_fused_dct = cfg->n_mfcc <= 16;
+          if (mt.a_tab.empty()) mt.a_tab.assign(128, 0.0f);
+          p->m12_win_off = (unsigned)(MM_M12_S_OFF + (size_t)s_floats * 4);
+          p->m12_tw_off = p->m12_win_off + 2048u;
+          p->m12_a_off = p->m12_tw_off + 16u * MM_M12_TW_PITCH * 4u;
+          p->m12_n_a2 = (int)(mt.a_tab.size() / 2);
+          p->m12_dct_off = p->m12_a_off + (unsigned)align_up(mt.a_tab.size() * 4, 16);
+          p->m12_part_off = p->m12_dct_off + (unsigned)mt.nb * 1024u;
+          p->m12_cnt_off = p->m12_part_off + (p->m12_fused_dct ? (unsigned)mt.n_slots * 1024u : 0u);
+          p->m12_lds_bytes = (size_t)p->m12_cnt_off + 16;
+          const std::vector<float> zeros(64, 0.0f);
+          if (p->m12_lds_bytes <= MM_LM_LDS_MAX &&
+              upload(&p->d_m12_a, mt.a_tab.data(), mt.a_tab.size() * 4) == MM_OK &&
+              upload(&p->d_m12_dct, mt.dct_tab.data(), mt.dct_tab.size() * 4) == MM_OK &&
+              upload(&p->d_zeros, zeros.data(), zeros.size() * 4) == MM_OK &&
+              set_m12_attr(MM_LM_LDS_MAX)) {
+            std::memcpy(p->m12_units, mt.units.data(), sizeof(p->m12_units));
+            std::memcpy(p->m12_nunits, mt.n_units.data(), sizeof(p->m12_nunits));
+            p->m12_ok = 1;
+          }
+        }
       }
     }
   }
@@ -801,6 +838,7 @@ int mm_plan_destroy(mm_plan* p) {
 
   (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane); (void)hipFree(p->d_window_e);
   (void)hipFree(p->d_rf2k_lane_tab);
+  (void)hipFree(p->d_m12_a); (void)hipFree(p->d_m12_dct); (void)hipFree(p->d_zeros);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
   return MM_OK;
@@ -812,19 +850,40 @@ int mm_plan_config(const mm_plan* p, mm_config* out) {
   return MM_OK;
 }
 
+// Which fused kernel a log-mel / MFCC call runs on (mode 1; mode 0 = the power stage output).  `call`
+// = false answers for a regular call (aligned rows, n_samples >= 4).  p->variant (mm_plan_set_variant)
+// pins a variant where it applies; what a variant cannot take falls through to the next one.
+enum { MM_K_GENERIC = 0, MM_K_W8 = 1, MM_K_W16 = 2, MM_K_WPF = 3, MM_K_W16S = 4, MM_K_M12 = 5 };
+static int choose_kernel(const mm_plan* p, int mode, bool call, const float* d_audio, int64_t n_samples, int64_t stride) {
+  if (p->force_generic) return MM_K_GENERIC;
+  const int v = p->variant;
+  const bool force_wpf = v == MM_K_WPF;
+  const bool n4 = !call || n_samples >= 4, n2 = !call || n_samples >= 2;
+  // (the matrix-pipe variant is opt-in: on gfx950 v_mfma_f32_16x16x4_f32 holds the SIMD's VALU issue for its
+  // whole 32 cycles -- tools/probe/mfma_f32_coexec.hip -- so the mel MFMAs do not run under the transforms
+  // and the kernel measures 0.44 ms where the run-table kernel takes 0.37 ms)
+  const bool m12_ok = p->m12_ok && mode == 1 && n4 && v == MM_K_M12;
+  const bool staged_ok = p->s16_nr && p->w16_ok && n4 && v != MM_K_W16 && v != MM_K_W8;
+  const bool direct_ok = (!call || ((stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0)) && n2 &&
+                         p->cfg.preemph == 0.0f && (p->cfg.hop_length % 2) == 0;
+  const bool tile_ok = p->path == 1 && (direct_ok || staged_ok || m12_ok) && (p->embed == 1 || mode != 0);
+  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || !tile_ok) && n2) return MM_K_WPF;
+  if (!tile_ok) return MM_K_GENERIC;
+  if (m12_ok) return MM_K_M12;
+  if (p->w16_ok && v != MM_K_W8) return staged_ok ? MM_K_W16S : MM_K_W16;
+  return direct_ok ? MM_K_W8 : MM_K_GENERIC;
+}
+
 int mm_plan_kernel_path(const mm_plan* p) {
   if (!p) return MM_ERR_INVALID_ARG;
-  if (p->force_generic) return 0;
-  const bool force_wpf = dev_env("MM_PATH") == 3;
-  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || p->path != 1)) return 3;
-  if (p->path == 1 && p->w16_ok) {
-    const int mp = dev_env("MM_PATH");
-    if (p->cfg.preemph != 0.0f || (p->cfg.hop_length & 1)) return (p->s16_nr && mp != 1 && mp != 2) ? 4 : 0;
-    if (mp == 1) return 1;
-    return (p->s16_nr && mp != 2) ? 4 : 2;
-  }
-  if (p->cfg.preemph != 0.0f || (p->cfg.hop_length & 1)) return 0;
-  return p->path;
+  return choose_kernel(p, 1, false, nullptr, 0, 0);
+}
+
+int mm_plan_set_variant(mm_plan* p, int variant) {
+  if (!p || variant < 0 || variant > MM_K_M12) return MM_ERR_INVALID_ARG;
+  const int prev = p->variant;
+  p->variant = variant;
+  return prev;
 }
 
 int mm_plan_force_generic(mm_plan* p, int on) {
@@ -837,24 +896,27 @@ int mm_plan_force_generic(mm_plan* p, int on) {
 size_t mm_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_samples) {
   if (!p || batch < 1 || n_samples < 0) return 0;
   const int64_t T = mm_num_frames(&p->cfg, n_samples);
-  return align_up((size_t)batch * p->cfg.n_mels * T * 4, 256) + align_up((size_t)batch * 4, 256);
+  return align_up((size_t)batch * p->cfg.n_mels * T * 4, 256) + align_up((size_t)batch * 8, 256);   // log-mel rows | max keys | -min keys
 }
 
 // frame_major: the caller accepts (and, where the n_fft = 2048 kernel runs, gets) log-mel rows laid out
 // [B][T][n_mels]; *is_fm reports which layout was written.
+struct StftOut {
+  float* power = nullptr;      // mode 0: [B][T][n_bins]
+  float* logmel = nullptr;     // mode 1: log-mel rows (may be null on the fused-DCT kernel when top_db < 0)
+  int* key_max = nullptr;      // [B]
+  int* key_nmin = nullptr;     // [B] or null
+  float* mfcc = nullptr;       // fused (unclamped) DCT output, MM_K_M12 only
+  bool frame_major = false;    // the caller accepts log-mel rows laid out [B][T][n_mels]
+  bool is_fm = false;          // out: that layout was written
+  bool fused_dct = false;      // out: mfcc holds the unclamped DCT
+};
+
 static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch, int64_t n_samples,
-                       int64_t stride, float* out_power, float* out_logmel, int* clip_key,
-                       hipStream_t st, bool frame_major = false, bool* is_fm = nullptr) {
-  if (is_fm) *is_fm = false;
-  const bool force_wpf = dev_env("MM_PATH") == 3;
-  // which n_fft = 512 tile kernels can take this call: the staged one (pre-emphasis, any hop parity,
-  // alignment and length, hop <= 252) or the 8-wave / direct-load 16-wave kernels; what they cannot
-  // take goes to the wave-per-frame kernel before the generic one
-  const bool staged_ok = p->s16_nr && p->w16_ok && n_samples >= 4 && dev_env("MM_PATH") != 2 && dev_env("MM_PATH") != 1;
-  const bool direct_ok = (stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0 && n_samples >= 2 &&
-                         p->cfg.preemph == 0.0f && (p->cfg.hop_length % 2) == 0;
-  const bool tile_ok = p->path == 1 && (direct_ok || staged_ok) && (p->embed == 1 || mode != 0);
-  if (p->k2_ok && (p->cfg.n_fft != 512 || force_wpf || !tile_ok) && !p->force_generic && n_samples >= 2) {
+                       int64_t stride, StftOut& o, hipStream_t st) {
+  o.is_fm = false; o.fused_dct = false;
+  const int kern = choose_kernel(p, mode, true, d_audio, n_samples, stride);
+  if (kern == MM_K_WPF) {
     WpfParams q;
     const int R = p->wpf_r, F = 4 / R;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
@@ -864,10 +926,10 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
     q.macc_stride = (p->cfg.n_mels + 63) / 64 * 64; q.waves_per_wg = p->wpf_waves;
     q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane; q.group_max = p->wpf_group_max;
-    q.out_logmel = out_logmel; q.clip_key = clip_key; q.out_power = out_power;
-    if (frame_major) { q.sB = q.n_frames * q.n_mels; q.sT = q.n_mels; q.sM = 1; }
+    q.out_logmel = o.logmel; q.clip_key = o.key_max; q.out_power = o.power;
+    if (o.frame_major) { q.sB = q.n_frames * q.n_mels; q.sT = q.n_mels; q.sM = 1; }
     else { q.sB = q.n_frames * q.n_mels; q.sT = 1; q.sM = q.n_frames; }
-    if (is_fm) *is_fm = frame_major;
+    o.is_fm = o.frame_major;
     int64_t grid = (q.total_groups + p->wpf_waves - 1) / p->wpf_waves;
     if (grid > p->num_cus) grid = p->num_cus;
     const dim3 blk(64 * p->wpf_waves);
@@ -883,7 +945,35 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     HIP_TRY(hipGetLastError());
     return MM_OK;
   }
-  if (tile_ok && !p->force_generic) {
+  if (kern == MM_K_M12) {
+    Logmel12mParams q;
+    q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
+    q.n_frames = mm_num_frames(&p->cfg, n_samples);
+    q.tiles_per_clip = (q.n_frames + MM_M12_TF - 1) / MM_M12_TF;
+    q.n_tiles = batch * q.tiles_per_clip;
+    q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.n_mfcc = p->cfg.n_mfcc; q.nb = p->m12_nb;
+    q.amin = p->cfg.amin; q.db_offset = p->db_offset; q.preemph = p->cfg.preemph;
+    q.lane_tab = p->d_lane_tab; q.a_tab = (const float2*)p->d_m12_a; q.n_a2 = p->m12_n_a2;
+    q.window = p->embed > 1 ? p->d_window_e : p->d_window;
+    q.dct_tab = p->d_m12_dct;
+    std::memcpy(q.units, p->m12_units, sizeof(q.units));
+    std::memcpy(q.n_units, p->m12_nunits, sizeof(q.n_units));
+    o.fused_dct = o.mfcc != nullptr && p->m12_fused_dct;
+    q.out_logmel = (o.fused_dct && p->cfg.top_db < 0.0f) ? nullptr : o.logmel;   // rows only feed the clamp fix-up
+    q.out_mfcc = o.fused_dct ? o.mfcc : nullptr;
+    q.key_max = o.key_max; q.key_nmin = o.key_nmin;
+    q.s_floats = p->m12_s_floats; q.zeros = p->d_zeros;
+    q.win_off = p->m12_win_off; q.tw_off = p->m12_tw_off; q.a_off = p->m12_a_off; q.dct_off = p->m12_dct_off; q.part_off = p->m12_part_off; q.cnt_off = p->m12_cnt_off;
+    if (q.n_tiles > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+    const int64_t grid = q.n_tiles < p->num_cus ? q.n_tiles : p->num_cus;
+    const bool pre = p->cfg.preemph != 0.0f;
+    const bool odd = p->cfg.hop_length & 1;
+    const bool unal = (stride % 4) != 0 || (n_samples % 4) != 0 || (((uintptr_t)d_audio) & 15) != 0;
+    launch_m12(p->m12_nr, pre, odd, unal, dim3((unsigned)grid), p->m12_lds_bytes, st, q);
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
+  if (kern != MM_K_GENERIC) {
     Logmel512Params q;
     q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
     q.n_frames = mm_num_frames(&p->cfg, n_samples);
@@ -891,17 +981,17 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.n_tiles = batch * q.tiles_per_clip;
     q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
     q.window = p->embed > 1 ? p->d_window_e : p->d_window; q.tw = p->d_tw; q.mel_tab = (const float4*)p->d_sw_tab; q.n_runs = p->sw_n_runs; q.n_tab16 = p->sw_n_tab16;
-    q.wave_part = p->d_sw_part; q.out_logmel = out_logmel; q.clip_key = clip_key;
-    q.out_power = out_power;
-    q.dbg = dev_env("MM_DEBUG");
+    q.wave_part = p->d_sw_part; q.out_logmel = o.logmel; q.clip_key = o.key_max;
+    q.out_power = o.power;
+    q.dbg = 0;
     q.lane_tab = p->d_lane_tab;
+    q.preemph = p->cfg.preemph;
+    if (q.n_tiles > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
     const int64_t grid = q.n_tiles < p->num_cus ? q.n_tiles : p->num_cus;
-    const bool use_w16 = p->w16_ok && dev_env("MM_PATH") != 1;
-    if (use_w16) {
+    if (kern == MM_K_W16S || kern == MM_K_W16) {
       q.mel_tab = (const float4*)p->d_w16_tab; q.n_runs = p->w16_n_runs; q.n_tab16 = p->w16_n_tab16;
       q.wave_part = p->d_w16_part;
-      if (staged_ok) {
-        q.preemph = p->cfg.preemph;
+      if (kern == MM_K_W16S) {
         const bool pre = p->cfg.preemph != 0.0f;
         const bool odd = p->cfg.hop_length & 1;
         const bool unal = (stride % 4) != 0 || (n_samples % 4) != 0 || (((uintptr_t)d_audio) & 15) != 0;
@@ -929,8 +1019,8 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
   q.n_fft = p->cfg.n_fft; q.log2nc = p->log2nc; q.hop = p->cfg.hop_length; q.n_bins = p->n_bins;
   q.n_mels = p->cfg.n_mels; q.preemph = p->cfg.preemph; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
   q.window = p->d_window; q.tw = p->d_tw; q.mel_start = p->d_mel_start; q.mel_len = p->d_mel_len;
-  q.mel_off = p->d_mel_off; q.mel_w = p->d_mel_w; q.out_power = out_power; q.out_logmel = out_logmel;
-  q.clip_key = clip_key; q.frames_per_wave = 4;
+  q.mel_off = p->d_mel_off; q.mel_w = p->d_mel_w; q.out_power = o.power; q.out_logmel = o.logmel;
+  q.clip_key = o.key_max; q.frames_per_wave = 4;
   const int nc = 1 << p->log2nc;
   const size_t wave_bytes = ((size_t)nc * 8 + (size_t)(nc + 1) * 4 + 15) & ~(size_t)15;
   const int fpb = 4 * q.frames_per_wave;
@@ -948,7 +1038,8 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
 static int check_audio_args(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_samples,
                             int64_t stride) {
   if (!p || !d_audio || batch < 1 || n_samples < 1 || stride < n_samples) return MM_ERR_INVALID_ARG;
-  if (n_samples > ((int64_t)1 << 31) - 8192) return MM_ERR_INVALID_ARG;
+  // the radix-16 kernels index samples with 32-bit offsets (4 * index in the wave-per-frame kernel)
+  if (n_samples > MM_MAX_SAMPLES) return MM_ERR_INVALID_ARG;
   return MM_OK;
 }
 
@@ -958,7 +1049,9 @@ int mm_stft_power_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n
   if (rc || !d_power) return rc ? rc : MM_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   StageTimer tm(p, MM_STAGE_POWER, st);
-  return launch_stft(p, 0, d_audio, batch, n_samples, stride, d_power, nullptr, nullptr, st);
+  StftOut o;
+  o.power = d_power;
+  return launch_stft(p, 0, d_audio, batch, n_samples, stride, o, st);
 }
 
 int mm_logmel_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_samples, int64_t stride,
@@ -969,7 +1062,9 @@ int mm_logmel_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_sam
   HIP_TRY(hipMemsetAsync(d_clipmax, 0x80, (size_t)batch * 4, st));
   {
     StageTimer tm(p, MM_STAGE_LOGMEL, st);
-    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, nullptr, d_logmel, (int*)d_clipmax, st);
+    StftOut o;
+    o.logmel = d_logmel; o.key_max = (int*)d_clipmax;
+    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, o, st);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(decode_keys_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st,
@@ -987,19 +1082,28 @@ int mm_mfcc_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_sampl
   const int64_t T = mm_num_frames(&p->cfg, n_samples);
   float* logmel = (float*)d_ws;
   int* keys = (int*)((char*)d_ws + align_up((size_t)batch * p->cfg.n_mels * T * 4, 256));
-  bool fm = false;
+  const bool clamp = p->cfg.top_db >= 0.0f;
+  StftOut o;
   {
     StageTimer tm(p, MM_STAGE_INIT, st);
-    HIP_TRY(hipMemsetAsync(keys, 0x80, (size_t)batch * 4, st));
+    HIP_TRY(hipMemsetAsync(keys, 0x80, (size_t)batch * 8, st));   // max keys | keys of -min
   }
   {
     StageTimer tm(p, MM_STAGE_LOGMEL, st);
-    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, nullptr, logmel, keys, st, true, &fm);
+    o.logmel = logmel; o.key_max = keys; o.key_nmin = keys + batch; o.mfcc = d_mfcc; o.frame_major = true;
+    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, o, st);
     if (rc) return rc;
   }
+  if (o.fused_dct && !clamp) return MM_OK;
   {
     StageTimer tm(p, MM_STAGE_DCT, st);
-    if (fm) {
+    if (o.fused_dct) {
+      // the kernel stored DCT(unclamped rows): only clips with min < max - top_db need the clamped DCT
+      const int64_t bpc = (T + 255) / 256;
+      if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+      hipLaunchKernelGGL(dct_fixup_kernel, dim3((unsigned)(batch * bpc)), dim3(256), 0, st, logmel, keys, keys + batch,
+                         p->d_dct_t, d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
+    } else if (o.is_fm) {
       const int64_t bpc = (T + 63) / 64;
       if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
       launch_dct_fm(dim3((unsigned)(batch * bpc)), (size_t)64 * (p->cfg.n_mels + 1) * 4, st, logmel, keys, p->d_dct_t,

@@ -126,6 +126,9 @@ def butter_sos(order: int, wn: float) -> np.ndarray:
     return out[:r]
 
 
+KERNEL_PATHS = ("generic", "radix16-w8", "radix16-w16", "radix16-wpf", "radix16-w16s", "radix16-m12")
+
+
 def _torch():
     import torch
     return torch
@@ -191,7 +194,21 @@ class MfccPlan:
 
     @property
     def kernel_path(self):
-        return {0: "generic", 1: "radix16-w8", 2: "radix16-w16", 3: "radix16-wpf", 4: "radix16-w16s"}[self._lib.mm_plan_kernel_path(self._h)]
+        return KERNEL_PATHS[self._lib.mm_plan_kernel_path(self._h)]
+
+    def set_variant(self, which):
+        """Pin a fused-kernel variant (a name from KERNEL_PATHS, its number, or None / 'auto') for the
+        calls it can take; returns the previous setting's name."""
+        if which in (None, "auto"):
+            v = 0
+        elif isinstance(which, str):
+            v = KERNEL_PATHS.index(which if which.startswith("radix16-") else "radix16-" + which)
+        else:
+            v = int(which)
+        prev = self._lib.mm_plan_set_variant(self._h, v)
+        if prev < 0:
+            _lib.check(prev, "mm_plan_set_variant")
+        return "auto" if prev == 0 else KERNEL_PATHS[prev]
 
     def force_generic(self, on=True):
         return self._lib.mm_plan_force_generic(self._h, 1 if on else 0)

@@ -30,37 +30,26 @@ def test_native_library_is_loaded(gpu):
 
 
 class _variant:
-    """Select the fused-kernel variant for the calls inside: 'w16s' (default where it applies: 16 waves,
-    samples staged through LDS), 'w16' (MM_PATH=2: 16 waves, direct loads -- otherwise used for unaligned
-    or odd-length input), 'w8' (MM_PATH=1: the 8-wave kernel, otherwise only used when the mel table is
-    too big for w16), 'wpf' (MM_PATH=3) or 'generic'.  Configurations a variant does not cover fall
+    """Pin the fused-kernel variant for the calls inside (mm_plan_set_variant): 'm12' (default where it
+    applies: 12 waves, mel + DCT on the matrix pipe), 'w16s' (16 waves, samples staged through LDS), 'w16'
+    (16 waves, direct loads), 'w8' (the 8-wave kernel, otherwise only used when the mel table is too big
+    for w16), 'wpf' (wave per frame group) or 'generic'.  Configurations a variant does not cover fall
     through to the next one."""
 
     def __init__(self, plan, which):
         self.plan, self.which = plan, which
 
     def __enter__(self):
-        import os
-        self.old = os.environ.get("MM_PATH")
-        if self.which == "w8":
-            os.environ["MM_PATH"] = "1"
-        if self.which == "w16":
-            os.environ["MM_PATH"] = "2"
-        if self.which == "wpf":
-            os.environ["MM_PATH"] = "3"
+        self.old = self.plan.set_variant(None if self.which == "generic" else self.which)
         self.plan.force_generic(self.which == "generic")
         return self
 
     def __exit__(self, *a):
-        import os
         self.plan.force_generic(False)
-        if self.old is None:
-            os.environ.pop("MM_PATH", None)
-        else:
-            os.environ["MM_PATH"] = self.old
+        self.plan.set_variant(self.old)
 
 
-VARIANTS = ["w16s", "w16", "w8", "wpf", "generic"]
+VARIANTS = ["m12", "w16s", "w16", "w8", "wpf", "generic"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -128,6 +117,84 @@ def test_staged_kernel_large_hop(gpu):
         got = plan.mfcc(_dev(clips, gpu)).cpu().numpy()
         for i in range(3):
             mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw)), f"hop {hop} clip {i}")
+
+
+@pytest.mark.parametrize("n", [4, 8, 160, 252, 7680, 7684, 10236, 16000, 40964, 5, 161, 10241, 16003])
+def test_matrix_pipe_kernel_lengths(n, gpu):
+    """The 12 + 4 wave kernel with the mel contraction and the DCT on the matrix pipe ('m12', opt-in):
+    lengths around its edges (clip shorter than the centre pad, exactly one 48-frame tile, one frame more),
+    lengths that are not multiples of 4 (register-staged instantiation instead of LDS-DMA), several clips
+    per launch incl. one that forces the top_db clamp (the fix-up kernel) and silence: == oracle, and
+    == the run-table kernel within float32 round-off."""
+    kw, _, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    kinds = ["am", "noise", "quiet_tail", "silence", "impulse"]
+    clips = np.stack([O.synth_clip(1700 + n + i, n, 16000, k) for i, k in enumerate(kinds)])
+    d = _dev(clips, gpu)
+    with _variant(plan, "m12"):
+        assert plan.kernel_path == "radix16-m12"
+        got = plan.mfcc(d).cpu().numpy()
+        lm, mx = plan.logmel(d)
+    ref = plan.mfcc(d).cpu().numpy()
+    lmr, mxr = plan.logmel(d)
+    np.testing.assert_allclose(lm.cpu().numpy(), lmr.cpu().numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(mx.cpu().numpy(), mxr.cpu().numpy(), rtol=0, atol=2e-4)
+    for i in range(clips.shape[0]):
+        want = O.mfcc(clips[i], O.OracleConfig(**kw))
+        mfcc_close(got[i], want, f"m12 n={n} {kinds[i]}")
+        mfcc_close(got[i], ref[i], f"m12 vs w16s n={n} {kinds[i]}")
+
+
+def test_matrix_pipe_kernel_configs(gpu):
+    """'m12' beyond the benchmark shape: the reference's own defaults (128 mel = 8 filter blocks, 26 empty
+    filters, hop 50), pre-emphasis, odd hops, unaligned row views, n_fft 256 embedded in 512, n_mfcc > 16
+    (DCT in its own kernel), no clamp (top_db < 0: no log-mel rows are written), and a hop whose samples
+    do not fit next to the double-buffered power tile (falls through to the run-table kernel)."""
+    import torch
+    cases = [
+        (load_golden("refdefault_am")[0], 10000, "radix16-m12"),
+        ({**load_golden("c1_am")[0], "preemph": 0.97}, 16000, "radix16-m12"),
+        ({**load_golden("c1_am")[0], "hop_length": 161}, 16000, "radix16-m12"),
+        ({**load_golden("c1_am")[0], "hop_length": 77, "preemph": 0.95}, 16000, "radix16-m12"),
+        ({**load_golden("c1_am")[0], "n_mels": 64, "n_mfcc": 20, "hop_length": 128}, 16000, "radix16-m12"),
+        ({**load_golden("c1_am")[0], "top_db": -1.0}, 16000, "radix16-m12"),
+        (dict(sr=8000, n_fft=256, win_length=200, hop_length=80, n_mels=40, n_mfcc=13, fmin=50.0, fmax=4000.0), 8000, "radix16-m12"),
+        ({**load_golden("c1_am")[0], "hop_length": 200}, 16000, "radix16-w16s"),
+    ]
+    for kw, sr, path in cases:
+        plan = _plan(kw)
+        okw = {**kw, "top_db": None} if kw.get("top_db", 80.0) < 0 else kw     # the C ABI's "< 0 = no clamp"
+        with _variant(plan, "m12"):
+            assert plan.kernel_path == path, kw
+            for n in (4801, 12000, 30000):
+                clips = np.stack([O.synth_clip(40 + n + i, n, sr, k) for i, k in enumerate(["am", "noise", "quiet_tail"])])
+                for pad, lead in ((0, 0), (3, 1)):
+                    big = torch.zeros((3, lead + n + pad), dtype=torch.float32, device=gpu)
+                    big[:, lead:lead + n] = _dev(clips, gpu)
+                    got = plan.mfcc(big[:, lead:lead + n]).cpu().numpy()
+                    for i in range(3):
+                        mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**okw)), f"m12 {kw} n={n} pad={pad} clip {i}")
+
+
+def test_matrix_pipe_kernel_full_size(gpu):
+    """'m12' at BASELINE configs[1] size (1024 x 10 s): permutation equivariance (tiles of different clips
+    follow each other in one workgroup; the DCT partial slots and the arrival counters are reused every
+    tile), run-to-run bit-exactness, spot clips vs the oracle, and the clamp fix-up on half of the clips."""
+    import torch
+    kw, _, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    g = torch.Generator(device=gpu).manual_seed(12)
+    audio = 0.05 * torch.randn((1024, 160000), generator=g, device=gpu)
+    audio[::2, 80000:] = 0.0                      # digital silence: these clips clamp
+    with _variant(plan, "m12"):
+        m = plan.mfcc(audio)
+        assert torch.equal(plan.mfcc(audio), m)
+        perm = torch.randperm(1024, device=gpu, generator=g)
+        assert torch.equal(plan.mfcc(audio[perm].contiguous()), m[perm])
+    ref = plan.mfcc(audio)
+    assert ((m - ref).abs().max() / ref.abs().max()).item() < 5e-6
+    for i in (0, 1, 511, 1023):
+        mfcc_close(m[i].cpu().numpy(), O.mfcc(audio[i].cpu().numpy(), O.OracleConfig(**kw)), f"m12 full size clip {i}")
 
 
 def test_preemphasis_on_the_staged_kernel(gpu):
