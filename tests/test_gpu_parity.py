@@ -247,7 +247,7 @@ def test_odd_hop_on_the_staged_kernel(gpu):
         for i in range(3):
             mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw)), f"odd hop {hop} clip {i}")
         with _variant(plan, "w16"):
-            assert plan.kernel_path == "generic"
+            assert plan.kernel_path == "radix16-wpf"      # the direct-load kernel needs an even hop: wave-per-frame kernel instead
 
 
 def test_kernel_variants_selected(gpu):
