@@ -13,9 +13,15 @@ Prints one JSON line (rank 0) with `value` = whole-job frames/s, plus
   roofline     -- the dominant kernel of the timed region (fused frame+window+rFFT+power+mel+log),
                   algorithmic bytes / average launch duration from HIP events on the launch stream;
   rfft_stage   -- the stage-isolated batched rFFT kernel (the "% HBM roofline (rFFT)" figure),
-                  measured in the same process right after the timed region;
+                  measured in the same process right after the timed region, beside a float4
+                  grid-stride device copy (mm_devcopy_f32) as the practical HBM ceiling;
+  c2, c4       -- BASELINE configs[1] (MFCC only) and configs[3] (48 kHz stereo, n_fft 2048, 80 mel,
+                  40 MFCC, batch 512) timed in the same process after the headline region (N = 1);
+  gather_full  -- N > 1: the literal north-star variant (every rank computes its modulation spectrum,
+                  MFCC + modulation spectrum travel in one gather) timed beside the default;
   cpu_baseline -- the NumPy oracle (a port of the reference's librosa path) on the host cores,
-                  bounded sample, rank 0 at N = 1 only.
+                  bounded sample, rank 0 at N = 1 only.  It runs FIRST, before anything touches the
+                  GPU (its worker pool is forked from a process that has not initialised HIP).
 """
 import argparse
 import json
@@ -28,30 +34,34 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
+C16K = dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0)
+C48K = dict(sr=48000, n_fft=2048, win_length=1200, hop_length=480, n_mels=80, n_mfcc=40, fmin=100.0, fmax=10000.0)
 WORKLOADS = {
-    # name: (clips per GPU, seconds, cfg kwargs, with_modspec)
-    "c3": (1024, 10.0, dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=40,
-                            n_mfcc=13, fmin=100.0, fmax=8000.0), True),
-    "c2": (1024, 10.0, dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=40,
-                            n_mfcc=13, fmin=100.0, fmax=8000.0), False),
-    "c4": (1024, 10.0, dict(sr=48000, n_fft=2048, win_length=1200, hop_length=480, n_mels=80,
-                            n_mfcc=40, fmin=100.0, fmax=10000.0), False),
+    # name: (BASELINE configs index, rows per GPU, channels, seconds, cfg kwargs, with_modspec)
+    "c3": (2, 1024, 1, 10.0, C16K, True),
+    "c2": (1, 1024, 1, 10.0, C16K, False),
+    "c4": (3, 512, 2, 10.0, C48K, False),
 }
 
 
-def pmc_traffic(stage):
-    """HBM bytes per launch of a stage's kernel from the newest committed rocprofv3 PMC summary
-    (profiles/*_pmc.csv, written by tools/summarize_prof.py from separate FETCH_SIZE / WRITE_SIZE
-    passes of this same command; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes).  None if absent."""
+def workload_label(name, B, T, cfg, n_mod):
+    idx, _, ch, secs, _, with_mod = WORKLOADS[name]
+    what = f"{B} clips" if ch == 1 else f"{B} stereo clips (both channels transformed = {B * ch} channel-rows [B, 2, n], row stride n)"
+    return (f"BASELINE configs[{idx}] per GPU: {what} x {secs:g} s x {cfg.sr:g} Hz, win {cfg.win_length} "
+            f"hop {cfg.hop_length} n_fft {cfg.n_fft}, {cfg.n_mels} mel, {cfg.n_mfcc} MFCC"
+            + (f" + modulation spectrum (rFFT {n_mod} over trajectories)" if with_mod else ""))
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary that lists it
+    (profiles/*_pmc.csv, written by tools/summarize_prof.py from separate FETCH_SIZE / WRITE_SIZE passes of
+    this same command; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes).  None if absent."""
     import csv
     import glob
-    key = {"logmel": "logmel512", "dct": "dct_clamp", "modspec": "rfft16_kernel<2", "rfft": "rfft16_kernel<1, true>"}.get(stage)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")))
-    if not key or not files:
-        return None, None
-    for r in csv.DictReader(open(files[-1])):
-        if key in r["Kernel"]:
-            return int(r["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")), reverse=True):
+        for r in csv.DictReader(open(f)):
+            if kernel_key in r["Kernel"]:
+                return int(r["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -68,6 +78,12 @@ def synth_batch(torch, device, batch, n, sr, seed0):
 
 # ---- CPU baseline (oracle) ------------------------------------------------------------------
 def _cpu_init():
+    # one thread per worker process: the BLAS / OpenMP pools must be limited BEFORE numpy is first imported
+    # in the worker (the parent has not imported it when it forks)
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[v] = "1"
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mfcc_oracle  # noqa: F401  (numpy / scipy load here, once per worker)
     try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(1)
@@ -75,17 +91,25 @@ def _cpu_init():
         pass
 
 
+_CLIPS = {}
+
+
 def _cpu_one(args):
-    clip, kw, with_mod = args
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    seed, n, kw, with_mod = args
     import mfcc_oracle as O
+    key = (seed % 4, n, kw["sr"])                       # four clips per worker, generated once (not in the timed work)
+    if key not in _CLIPS:
+        _CLIPS[key] = O.synth_clip(seed % 4, n, kw["sr"], "am")   # the GPU batch's signal model
+    clip = _CLIPS[key]
+    t0 = time.perf_counter()
     m = O.mfcc(clip, O.OracleConfig(**kw))
     if with_mod:
         O.modspec(m)
-    return m.shape[1]
+    return m.shape[1], time.perf_counter() - t0
 
 
-def cpu_baseline(clips_np, kw, with_mod, budget_s=12.0):
+def cpu_baseline(kw, n, with_mod, budget_s=12.0):
+    """Runs before the first GPU call: fork()ing workers from a HIP-initialised parent is not safe."""
     import multiprocessing as mp
     try:
         cores = len(os.sched_getaffinity(0))
@@ -94,20 +118,72 @@ def cpu_baseline(clips_np, kw, with_mod, budget_s=12.0):
     cores = max(1, min(cores, 16))   # a 1-GPU box's CPU share is 16 cores (the node shows 256)
     ctx = mp.get_context("fork")
     with ctx.Pool(cores, initializer=_cpu_init) as pool:
-        pool.map(_cpu_one, [(clips_np[0], kw, with_mod)] * cores)           # warm-up / page-in
+        pool.map(_cpu_one, [(i, n, kw, with_mod) for i in range(4 * cores)], chunksize=4)   # warm-up: clips generated, pages in
         t0 = time.perf_counter()
-        frames = sum(pool.map(_cpu_one, [(clips_np[i % len(clips_np)], kw, with_mod) for i in range(cores)]))
+        pool.map(_cpu_one, [(100 + i, n, kw, with_mod) for i in range(cores)])
         dt1 = time.perf_counter() - t0
         rounds = max(1, min(2000, int(budget_s / max(dt1, 1e-3))))
         n_clips = cores * rounds
         t0 = time.perf_counter()
-        frames = sum(pool.map(_cpu_one, [(clips_np[i % len(clips_np)], kw, with_mod) for i in range(n_clips)],
-                              chunksize=1))
+        res = pool.map(_cpu_one, [(1000 + i, n, kw, with_mod) for i in range(n_clips)], chunksize=1)
         dt = time.perf_counter() - t0
+    frames = sum(r[0] for r in res)
+    busy = sum(r[1] for r in res)
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_clips} clips x {frames // n_clips} frames (same synthetic clips as the GPU "
-                      f"run), NumPy oracle of the librosa path, {cores} worker processes x 1 thread, "
-                      f"{dt:.1f} s"}
+            "sample": f"{n_clips} clips x {frames // n_clips} frames (the GPU run's signal model, four clips per worker generated "
+                      f"beforehand), NumPy oracle of the librosa path, {cores} worker processes x "
+                      f"1 thread, {dt:.1f} s wall, {busy:.0f} core-seconds in the path"}
+
+
+def time_steps(torch, plan, fn, steps, warmup, stages, sync=None):
+    """warmup untimed + `steps` timed calls of fn; HIP events around `stages` only inside the timed region,
+    the other stages from a short pass afterwards.  Returns (seconds, {stage: (ms_sum, launches)})."""
+    for _ in range(warmup):
+        fn()
+    if sync:
+        sync()
+    torch.cuda.synchronize()
+    plan.timing_enable(True, stages=stages)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    if sync:
+        sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    plan.timing_enable(False)
+    stage = plan.timing_read()
+    plan.timing_enable(True)
+    for _ in range(min(steps, 5)):
+        fn()
+    if sync:
+        sync()
+    torch.cuda.synchronize()
+    plan.timing_enable(False)
+    for k, v in plan.timing_read().items():
+        if k not in stages:
+            stage[k] = v
+    return dt, stage
+
+
+def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=None):
+    alg = {
+        # unique audio in + log-mel out (+ the unclamped MFCC rows where the kernel also applies the DCT)
+        "logmel": 4 * cfg.hop_length + 4 * cfg.n_mels + (4 * cfg.n_mfcc if fused_dct else 0),
+        "dct": 4 * cfg.n_mels + 4 * cfg.n_mfcc,            # log-mel in + MFCC out
+        "modspec": (4 * T + 8 * (n_mod // 2 + 1)) * cfg.n_mfcc / T if with_mod else 0,
+    }
+    dom = max(per_stage, key=lambda k: per_stage[k]["avg_ms"])
+    if dom not in alg:
+        return None
+    bytes_launch = alg[dom] * B * T
+    ach = bytes_launch / (per_stage[dom]["avg_ms"] * 1e-3) / 1e9
+    traffic, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
+    return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_frame": alg[dom],
+            "avg_launch_ms": per_stage[dom]["avg_ms"]}
 
 
 def main():
@@ -118,23 +194,15 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--clips", type=int, default=0, help="override clips per GPU (debug)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c4 / rFFT-stage passes (profiling runs)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernels")
+    ap.add_argument("--variant", default=None, help="pin a fused-kernel variant (m12, w16s, w16, w8, wpf): development A/B")
     ap.add_argument("--gather", default="mfcc", choices=["mfcc", "full"],
                     help="N > 1: 'mfcc' gathers the MFCC slab and the root computes the modulation spectrum of the "
                          "gathered trajectories (default: half the bytes over xGMI); 'full': every rank computes its "
-                         "own modulation spectrum and both arrays are gathered")
+                         "own modulation spectrum and both arrays are gathered.  The other variant is timed too and "
+                         "reported under 'gather_other'")
     a = ap.parse_args()
-
-    # Anything libraries print on stdout (RCCL prints a version banner there at communicator init)
-    # goes to stderr: stdout carries exactly ONE line, the JSON result.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-
-    import torch
-    import torch.distributed as dist
-    from modulation_mfcc_amd import MfccConfig, MfccPlan
-    from modulation_mfcc_amd.dist import PipelinedGather, SlabLayout
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -143,27 +211,57 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # before anything initialises HIP/HSA: the host driver only supports dmabuf IPC
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    use_dist = world > 1 or bool(os.environ.get("MM_BENCH_FORCE_DIST"))
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+
+    # Anything libraries print on stdout (RCCL prints a version banner there at communicator init)
+    # goes to stderr: stdout carries exactly ONE line, the JSON result.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    idx, B, ch, secs, kw, with_mod = WORKLOADS[a.workload]
+    if a.clips:
+        B = a.clips
+    cpu = None
+    if world == 1 and rank == 0 and not a.no_cpu:
+        cpu = cpu_baseline(kw, int(secs * kw["sr"]), with_mod)      # no torch / HIP yet in this process
+
+    import torch
+    import torch.distributed as dist
+    from modulation_mfcc_amd import MfccConfig, MfccPlan, _lib
+    from modulation_mfcc_amd.dist import PipelinedGather, SlabLayout
+
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # MM_BENCH_FORCE_DIST=1: take the N>1 code path (process group, pipelined gather) even with a
     # single rank -- a rehearsal of that path on a 1-GPU box
-    use_dist = world > 1 or bool(os.environ.get("MM_BENCH_FORCE_DIST"))
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
-    B, secs, kw, with_mod = WORKLOADS[a.workload]
-    if a.clips:
-        B = a.clips
-    cfg = MfccConfig(**kw)
-    n = int(secs * cfg.sr)
-    T = cfg.num_frames(n)
-    plan = MfccPlan(cfg)
-    if a.generic:
-        plan.force_generic(True)
-    audio = synth_batch(torch, dev, B, n, cfg.sr, seed0=1000 * rank)
+    def make(name, rows_override=0):
+        _, b, c, s, k, wm = WORKLOADS[name]
+        if rows_override:
+            b = rows_override
+        cfg = MfccConfig(**k)
+        n = int(s * cfg.sr)
+        plan = MfccPlan(cfg)
+        if a.generic:
+            plan.force_generic(True)
+        if a.variant:
+            plan.set_variant(a.variant)
+        audio = synth_batch(torch, dev, b * c, n, cfg.sr, seed0=1000 * rank)
+        if c > 1:                      # [B, ch, n]: the rows the kernels see are the channels, stride n
+            audio = audio.view(b, c, n)
+        return cfg, plan, audio, n, cfg.num_frames(n)
+
+    cfg, plan, audio, n, T = make(a.workload, a.clips)
+    rows = audio.reshape(-1, n)
+    R = rows.shape[0]
 
     # one flat output slab per rank so that a single gather per step moves everything; with N > 1
     # the slabs are double-buffered and the gather of step k runs on a side stream under the
@@ -171,154 +269,154 @@ def main():
     # N > 1, --gather mfcc: the modulation spectrum is a linear map of the MFCC trajectories, so only
     # the MFCC slab travels and the root runs ONE trajectory rFFT over the gathered block on the
     # gather's side stream (modulation_mfcc_amd/dist.py)
-    mod_on_root = use_dist and with_mod and a.gather == "mfcc"
-    lay = SlabLayout.make(cfg, B, n, with_mod and not mod_on_root)
     n_mod = cfg.mod_fft_len(T) if with_mod else 0
-    pg = PipelinedGather(lay.numel, dev) if use_dist else None
-    slab1 = torch.empty(lay.numel, dtype=torch.float32, device=dev) if not use_dist else None
-    plan.workspace(B, n)
-    mod_all = None
-    if mod_on_root and rank == 0:
-        mod_all = [torch.empty((world * B, cfg.n_mfcc, n_mod // 2 + 1), dtype=torch.complex64, device=dev)
-                   for _ in range(pg.depth)]
+    plan.workspace(R, n)
 
-    def root_modspec(i):        # runs inside the gather's side stream, root only
-        got = pg.recv_block[i][:, :lay.mfcc_numel].reshape(world * B, cfg.n_mfcc, T)
-        plan.modspec(got, out=mod_all[i])
+    def run_variant(gather_mode, steps, warmup):
+        mod_on_root = use_dist and with_mod and gather_mode == "mfcc"
+        lay = SlabLayout.make(cfg, R, n, with_mod and not mod_on_root)
+        pg = PipelinedGather(lay.numel, dev) if use_dist else None
+        slab1 = torch.empty(lay.numel, dtype=torch.float32, device=dev) if not use_dist else None
+        mod_all = None
+        if mod_on_root and rank == 0:
+            mod_all = [torch.empty((world * R, cfg.n_mfcc, n_mod // 2 + 1), dtype=torch.complex64, device=dev)
+                       for _ in range(pg.depth)]
 
-    def step():
-        slab = pg.acquire() if pg else slab1
-        mfcc_out, mod_out = lay.views(slab)
-        plan.mfcc(audio, out=mfcc_out)
-        if with_mod and not mod_on_root:
-            plan.modspec(mfcc_out, out=mod_out)
-        if pg:
-            pg.submit(post=root_modspec if mod_on_root else None)
+        def root_modspec(i):        # runs inside the gather's side stream, root only
+            got = pg.recv_block[i][:, :lay.mfcc_numel].reshape(world * R, cfg.n_mfcc, T)
+            plan.modspec(got, out=mod_all[i])
 
-    def drain():
-        if pg:
-            pg.finish()
+        def step():
+            slab = pg.acquire() if pg else slab1
+            mfcc_out, mod_out = lay.views(slab)
+            plan.mfcc(rows, out=mfcc_out)
+            if with_mod and not mod_on_root:
+                plan.modspec(mfcc_out, out=mod_out)
+            if pg:
+                pg.submit(post=root_modspec if mod_on_root else None)
 
-    for _ in range(a.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    # HIP events around the dominant kernel only inside the timed region (two hipEventRecord per timed
-    # launch cost ~5 us of stream time: all four kernels timed = 4 % of a step); the other kernels'
-    # durations come from a short untimed pass afterwards
-    plan.timing_enable(True, stages=["logmel"])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    plan.timing_enable(False)
-    stage = plan.timing_read()
-    plan.timing_enable(True)
-    for _ in range(min(a.steps, 5)):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    plan.timing_enable(False)
-    for k, v in plan.timing_read().items():
-        if k != "logmel":
-            stage[k] = v
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        def drain():
+            if pg:
+                pg.finish()
+            if use_dist:
+                dist.barrier()
 
-    frames_total = world * B * T * a.steps
+        dt, stage = time_steps(torch, plan, step, steps, warmup, ["logmel"], sync=drain)
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        if pg is not None and rank == 0 and os.environ.get("MM_BENCH_FORCE_DIST"):
+            # rehearsal check: what arrived at the root is what the last steps produced
+            last = (pg.k - 1) % pg.depth
+            assert torch.equal(pg.received[last][0], pg.slabs[last]), "gathered slab differs"
+        return dt, stage, mod_on_root
+
+    dt, stage, mod_on_root = run_variant(a.gather, a.steps, a.warmup)
+    frames_total = world * R * T * a.steps
     res = {
         "metric": "MFCC+mod-spectrum frames/sec" if with_mod else "MFCC frames/sec",
         "value": frames_total / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{'2' if with_mod else '1'}] per GPU: {B} clips x "
-                               f"{secs:g} s x {cfg.sr:g} Hz, win {cfg.win_length} hop {cfg.hop_length} "
-                               f"n_fft {cfg.n_fft}, {cfg.n_mels} mel, {cfg.n_mfcc} MFCC"
-                               + (f" + modulation spectrum (rFFT {n_mod} over trajectories)" if with_mod else ""),
+        "config": {"workload": workload_label(a.workload, B, T, cfg, n_mod),
                    "frames_per_clip": T, "clips_total": world * B, "kernel_path": plan.kernel_path,
                    "parallelism": f"clips sharded x{world}" + (", one RCCL gather per step (overlapped with the next step's kernels)" if world > 1 else "")
                                   + ("; MFCC slab gathered, modulation spectrum of the gathered trajectories computed on the root" if mod_on_root else ""),
-                   "gather": (a.gather if use_dist else None)},
+                   "gather": (a.gather if use_dist else None),
+                   "hsa_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
     }
+    if use_dist and with_mod:
+        other = "full" if a.gather == "mfcc" else "mfcc"
+        dt2, _, _ = run_variant(other, max(3, a.steps // 2), 2)
+        k2 = max(3, a.steps // 2)
+        if rank == 0:
+            res["gather_other"] = {"gather": other, "value": world * R * T * k2 / dt2, "unit": "frames/s",
+                                   "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
+                                   "note": "'full' = the literal north-star split: every rank computes its own modulation "
+                                           "spectrum and MFCC + modulation spectrum travel in the one gather"}
 
     if rank == 0:
         # ---- roofline of the dominant kernel, from HIP events recorded around every launch -----
+        fused = plan.kernel_path == "radix16-m12" and cfg.n_mfcc <= 16
         per_stage = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in stage.items()}
         res["kernels_ms"] = {k: round(v["avg_ms"], 4) for k, v in per_stage.items()}
-        dom = max(per_stage, key=lambda k: per_stage[k]["avg_ms"])
-        alg_bytes_per_frame = {
-            "logmel": 4 * cfg.hop_length + 4 * cfg.n_mels,     # unique audio in + log-mel out
-            "dct": 4 * cfg.n_mels + 4 * cfg.n_mfcc,            # log-mel in + MFCC out
-            "modspec": (4 * T + 8 * (n_mod // 2 + 1)) * cfg.n_mfcc / T if with_mod else 0,
-        }
-        if dom in alg_bytes_per_frame:
-            bytes_launch = alg_bytes_per_frame[dom] * B * T
-            ach = bytes_launch / (per_stage[dom]["avg_ms"] * 1e-3) / 1e9
-            traffic, src = pmc_traffic(dom) if a.workload == "c3" else (None, None)
-            res["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": src, "algorithmic_bytes_per_launch": bytes_launch,
-                               "algorithmic_bytes_per_frame": alg_bytes_per_frame[dom],
-                               "avg_launch_ms": per_stage[dom]["avg_ms"]}
+        key = {"radix16-w16s": "logmel512s", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(plan.kernel_path)
+        rl = roofline_of(cfg, R, T, n_mod, with_mod, per_stage, fused, key)
+        if rl:
+            res["roofline"] = rl
 
-        # ---- stage-isolated batched rFFT (frames in -> complex bins out), same process ---------
-        rows = B * T
-        frames_buf = torch.randn((rows, cfg.n_fft), device=dev, dtype=torch.float32)
-        spec = torch.empty((rows, cfg.n_bins), dtype=torch.complex64, device=dev)
-        for _ in range(3):
-            plan.rfft(frames_buf, cfg.n_fft, out=spec)
-        torch.cuda.synchronize()
-        plan.timing_enable(True)
-        for _ in range(10):
-            plan.rfft(frames_buf, cfg.n_fft, out=spec)
-        plan.timing_enable(False)
-        ms, cnt = plan.timing_read()["rfft"]
-        bpf = 4 * cfg.n_fft + 8 * cfg.n_bins
-        ach = rows * bpf / (ms / cnt * 1e-3) / 1e9
-        res["rfft_stage"] = {"kernel": "batched rFFT-%d, %d rows" % (cfg.n_fft, rows), "bound": "hbm",
-                             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": bpf,
-                             "frames_per_s": rows / (ms / cnt * 1e-3), "avg_launch_ms": ms / cnt}
-        # practical HBM ceiling of this device: a plain device-to-device copy (bytes read + written)
-        src_c = frames_buf.view(-1)[: (1 << 28)]              # 1 GiB
-        dst_c = torch.empty_like(src_c)
-        for _ in range(2):
-            dst_c.copy_(src_c)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            dst_c.copy_(src_c)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 5 * 2 * src_c.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        res["rfft_stage"]["device_copy_GBs"] = copy_gbs
-        res["rfft_stage"]["frac_of_device_copy"] = ach / copy_gbs
-        if "roofline" in res:
-            res["roofline"]["device_copy_GBs"] = copy_gbs
-        del frames_buf, spec, src_c, dst_c
+        if not a.no_extra:
+            # ---- stage-isolated batched rFFT (frames in -> complex bins out), same process ---------
+            nrows = R * T
+            frames_buf = torch.randn((nrows, cfg.n_fft), device=dev, dtype=torch.float32)
+            spec = torch.empty((nrows, cfg.n_bins), dtype=torch.complex64, device=dev)
+            for _ in range(3):
+                plan.rfft(frames_buf, cfg.n_fft, out=spec)
+            torch.cuda.synchronize()
+            plan.timing_enable(True)
+            for _ in range(10):
+                plan.rfft(frames_buf, cfg.n_fft, out=spec)
+            plan.timing_enable(False)
+            ms, cnt = plan.timing_read()["rfft"]
+            bpf = 4 * cfg.n_fft + 8 * cfg.n_bins
+            ach = nrows * bpf / (ms / cnt * 1e-3) / 1e9
+            res["rfft_stage"] = {"kernel": "batched rFFT-%d, %d rows" % (cfg.n_fft, nrows), "bound": "hbm",
+                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": bpf,
+                                 "frames_per_s": nrows / (ms / cnt * 1e-3), "avg_launch_ms": ms / cnt}
+            # practical HBM ceiling of this device: float4 grid-stride copy kernel of the library (bytes
+            # read + written), on the same stream, timed with events
+            src_c = frames_buf.view(-1)[: (1 << 28)]              # 1 GiB
+            dst_c = torch.empty_like(src_c)
+            lib = _lib.load()
+            st = torch.cuda.current_stream(dev).cuda_stream
+            for _ in range(2):
+                _lib.check(lib.mm_devcopy_f32(src_c.data_ptr(), dst_c.data_ptr(), src_c.numel(), st), "mm_devcopy_f32")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                lib.mm_devcopy_f32(src_c.data_ptr(), dst_c.data_ptr(), src_c.numel(), st)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * src_c.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            res["rfft_stage"]["device_copy_GBs"] = copy_gbs
+            res["rfft_stage"]["frac_of_device_copy"] = ach / copy_gbs
+            if "roofline" in res:
+                res["roofline"]["device_copy_GBs"] = copy_gbs
+            del frames_buf, spec, src_c, dst_c
 
-        if world == 1 and not a.no_cpu:
-            ns = min(B, 64)
-            res["cpu_baseline"] = cpu_baseline(audio[:ns].cpu().numpy(), kw, with_mod)
+            # ---- the other single-GPU configurations, same process (N = 1 only) --------------------
+            if world == 1:
+                for name in ("c2", "c4"):
+                    if name == a.workload:
+                        continue
+                    del audio, rows
+                    torch.cuda.empty_cache()
+                    c2, p2, audio, n2, T2 = make(name)
+                    rows = audio.reshape(-1, n2)
+                    R2 = rows.shape[0]
+                    out2 = torch.empty((R2, c2.n_mfcc, T2), dtype=torch.float32, device=dev)
+                    p2.workspace(R2, n2)
+                    k = max(5, a.steps // 2)
+                    dt2, st2 = time_steps(torch, p2, lambda: p2.mfcc(rows, out=out2), k, 2, ["logmel"])
+                    ps = {kk: {"avg_ms": v[0] / v[1], "launches": v[1]} for kk, v in st2.items()}
+                    key2 = {"radix16-w16s": "logmel512s", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(p2.kernel_path)
+                    res[name] = {"workload": workload_label(name, WORKLOADS[name][1], T2, c2, 0),
+                                 "metric": "MFCC frames/sec", "value": R2 * T2 * k / dt2, "unit": "frames/s",
+                                 "ms_per_step": 1e3 * dt2 / k, "steps": k, "kernel_path": p2.kernel_path,
+                                 "kernels_ms": {kk: round(v["avg_ms"], 4) for kk, v in ps.items()},
+                                 "roofline": roofline_of(c2, R2, T2, 0, False, ps, False, key2)}
+                    del out2
+
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)
         os.dup2(2, 1)
 
     if use_dist:
-        if pg is not None and rank == 0 and os.environ.get("MM_BENCH_FORCE_DIST"):
-            # rehearsal check: what arrived at the root is what the last steps produced
-            last = (pg.k - 1) % pg.depth
-            assert torch.equal(pg.received[last][0], pg.slabs[last]), "gathered slab differs"
         dist.barrier()
         dist.destroy_process_group()
 

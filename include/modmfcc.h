@@ -172,6 +172,11 @@ int64_t mm_rms_num_frames(int64_t n_samples, int32_t frame_length, int32_t hop_l
 int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t audio_stride,
                int32_t frame_length, int32_t hop_length, int32_t center, float* d_rms, void* stream);
 
+/* Measurement aid: float4 grid-stride device-to-device copy of n_floats (a multiple of 4; 16-byte
+ * aligned pointers) on `stream` -- the practical HBM ceiling bench.py quotes beside the stage-isolated
+ * rFFT figure.  No reference counterpart. */
+int mm_devcopy_f32(const float* d_src, float* d_dst, int64_t n_floats, void* stream);
+
 /* ---- per-kernel device timing (hipEvents on the launch stream) ------------------------- */
 /* on = 0: off; 1: every stage; otherwise a mask with bit (MM_STAGE_x + 1) set for each stage to time
  * (two hipEventRecord per timed launch: timing fewer stages perturbs the stream less). */

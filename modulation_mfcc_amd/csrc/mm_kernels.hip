@@ -1369,6 +1369,28 @@ int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t s
   return MM_OK;
 }
 
+// Measurement aid (bench.py): float4 grid-stride device-to-device copy on the caller's stream -- the
+// practical HBM ceiling the stage-isolated rFFT figure is compared with (MI355X_MICROARCH.md quotes
+// 6.29 TB/s for this shape of kernel).  n_floats must be a multiple of 4, pointers 16-byte aligned.
+__global__ __launch_bounds__(256) void devcopy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + 256 * u < n4) v[u] = src[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + 256 * u < n4) dst[i + 256 * u] = v[u];
+  }
+}
+
+int mm_devcopy_f32(const float* d_src, float* d_dst, int64_t n_floats, void* stream) {
+  if (!d_src || !d_dst || n_floats < 4 || (n_floats & 3) || (((uintptr_t)d_src | (uintptr_t)d_dst) & 15)) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(devcopy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)d_src, (float4*)d_dst,
+                     n_floats / 4);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
 int mm_timing_enable(mm_plan* p, int on) {
   if (!p) return MM_ERR_INVALID_ARG;
   p->timing_on = on;

@@ -527,6 +527,35 @@ def test_full_size_properties(gpu):
     assert torch.allclose(e_time, e_freq, rtol=1e-4)
 
 
+def test_full_size_c4_stereo(gpu):
+    """BASELINE configs[3] at full size: a [512, 2, 480000] stereo tensor (48 kHz, 10 s), n_fft 2048 / 80 mel
+    / 40 MFCC.  Each channel goes through the STRIDED-row path (audio[:, ch, :], row stride 2 n -- the
+    reference picks one channel, script/mfcc.py:377-380) and all 1024 channel-rows through the contiguous
+    path: spot clips vs the oracle, strided == contiguous bit for bit, permutation equivariance, finite."""
+    import torch
+    kw, _, _ = load_golden("c4_am")
+    plan = _plan(kw)
+    assert plan.kernel_path == "radix16-wpf"
+    B, n = 512, 480000
+    g = torch.Generator(device=gpu).manual_seed(4)
+    t = torch.arange(n, device=gpu, dtype=torch.float32) / 48000.0
+    base = 0.3 * torch.sin(2 * np.pi * 220 * t) * (1 + 0.5 * torch.sin(2 * np.pi * 4 * t))
+    audio = 0.05 * torch.randn((B, 2, n), generator=g, device=gpu)
+    audio += base[None, None, :]
+    audio[:, 1, :] *= 0.5                                   # the two channels differ
+    allrows = plan.mfcc(audio.view(2 * B, n))               # [1024, 40, 1001]
+    assert allrows.shape == (2 * B, 40, 1001) and bool(torch.isfinite(allrows).all())
+    for ch in (0, 1):
+        view = audio[:, ch, :]
+        assert view.stride(0) == 2 * n and not view.is_contiguous()
+        m = plan.mfcc(view)
+        assert torch.equal(m, allrows[ch::2])
+        for i in (0, 255, 511):
+            mfcc_close(m[i].cpu().numpy(), O.mfcc(view[i].cpu().numpy(), O.OracleConfig(**kw)), f"c4 ch {ch} clip {i}")
+    perm = torch.randperm(B, device=gpu, generator=g)
+    assert torch.equal(plan.mfcc(audio[perm][:, 0, :]), allrows[0::2][perm])
+
+
 def test_drop_in_get_MFCCS_change(gpu):
     from modulation_mfcc_amd import get_MFCCS_change
     kw, y, exp = load_golden("refdefault_am")
