@@ -338,7 +338,8 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel, from HIP events recorded around every launch -----
-        fused = plan.kernel_path == "radix16-m12" and cfg.n_mfcc <= 16
+        # the n_fft 512 tile kernels also apply the (unclamped) DCT: their launch stores the MFCC rows too
+        fused = plan.fused_dct
         per_stage = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in stage.items()}
         res["kernels_ms"] = {k: round(v["avg_ms"], 4) for k, v in per_stage.items()}
         key = {"radix16-w16s": "logmel512s", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(plan.kernel_path)
@@ -406,7 +407,7 @@ def main():
                                  "metric": "MFCC frames/sec", "value": R2 * T2 * k / dt2, "unit": "frames/s",
                                  "ms_per_step": 1e3 * dt2 / k, "steps": k, "kernel_path": p2.kernel_path,
                                  "kernels_ms": {kk: round(v["avg_ms"], 4) for kk, v in ps.items()},
-                                 "roofline": roofline_of(c2, R2, T2, 0, False, ps, False, key2)}
+                                 "roofline": roofline_of(c2, R2, T2, 0, False, ps, p2.fused_dct, key2)}
                     del out2
 
         if cpu is not None:

@@ -122,6 +122,13 @@ int mm_plan_config(const mm_plan* plan, mm_config* out);
  * the 160 KB of LDS) -- opt-in (mm_plan_set_variant): measured slower than variant 4, see DESIGN.md.  n_fft 64 / 128 / 256 plans use the n_fft 512
  * variants too (frames zero-padded to 512 points: same power at every (512/n_fft)-th bin). */
 int mm_plan_kernel_path(const mm_plan* plan);
+/* 1 if mm_mfcc_f32 of this plan applies the DCT-II inside the log-mel kernel (variants 4 and 5: the DCT
+ * of the unclamped rows, followed by a fix-up launch that redoes only the clips whose minimum lies more
+ * than top_db under their maximum), 0 if it runs the separate clamp + DCT kernel. */
+int mm_plan_fused_dct(const mm_plan* plan);
+/* on = 0: always run the separate clamp + DCT kernel (A/B measurements, cross-checks); returns the
+ * previous setting.  Default on. */
+int mm_plan_set_fuse_dct(mm_plan* plan, int on);
 /* force the generic kernels (debug / cross-check); returns previous value */
 int mm_plan_force_generic(mm_plan* plan, int on);
 /* pin one of the variants above (1..5) for the calls it can take, 0 = automatic choice; returns the

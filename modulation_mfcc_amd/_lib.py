@@ -73,6 +73,8 @@ PROTOTYPES = {
     "mm_plan_destroy": (C.c_int, [_vp]),
     "mm_plan_config": (C.c_int, [_vp, _cfgp]),
     "mm_plan_kernel_path": (C.c_int, [_vp]),
+    "mm_plan_fused_dct": (C.c_int, [_vp]),
+    "mm_plan_set_fuse_dct": (C.c_int, [_vp, C.c_int]),
     "mm_plan_force_generic": (C.c_int, [_vp, C.c_int]),
     "mm_plan_set_variant": (C.c_int, [_vp, C.c_int]),
     "mm_workspace_bytes": (C.c_size_t, [_vp, _i64, _i64]),

@@ -20,7 +20,8 @@ struct MelSweep {
   std::vector<int> d;
   std::vector<int> part;  // [n_waves][4] = {k_begin, k_end, m_begin, m_end}
 };
-bool build_mel_sweep(const mm_config& c, const float* dense, int n_waves, MelSweep* out);
+// weights (optional, [n_waves]): relative share of the sweep cost each wave should get (default: equal)
+bool build_mel_sweep(const mm_config& c, const float* dense, int n_waves, MelSweep* out, const double* weights = nullptr);
 
 // Run form of the sweep for the fused kernel's phase B.  A "run" is the set of bins with one value
 // of d; per wave the runs d = m_begin-1 .. m_end-1 are listed in order.  Bins are handled in

@@ -74,6 +74,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+typedef float mm_f32x4 __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f32_16x16x4_f32
+
 // In-place radix-2 DIT over a wave-private LDS buffer; input already bit-reversed.
 __device__ __forceinline__ void wave_cfft_lds(float2* z, int log2nc, const float2* __restrict__ tw,
                                               int lane) {
@@ -302,6 +310,14 @@ struct mm_plan {
   size_t w16_lds_bytes;
   int s16_nr;                      // staged-sample variant: 16-byte groups per thread and tile (0: not usable)
   size_t s16_lds_bytes;
+  // staged-sample variant with the (unclamped) DCT fused in: its own run table (four half-size parts for the
+  // DCT waves), DCT A operands, LDS layout
+  float *d_s16f_tab, *d_s16f_dcta;
+  int* d_s16f_part;
+  int s16f_ok, s16f_n_runs, s16f_n_tab16, s16f_lt_rows, s16f_nk, s16f_kb;
+  unsigned s16f_lt_off, s16f_dcta_off;
+  unsigned long long s16f_roles;
+  size_t s16f_lds_bytes;
   // 12-wave MFMA-mel variant (mm_logmel12m.hip.inc)
   float *d_m12_a, *d_m12_dct, *d_zeros;
   int m12_units[MM_M12_MW * MM_M12_UMAX * 4], m12_nunits[8];
@@ -310,6 +326,7 @@ struct mm_plan {
   int m12_n_a2;
   size_t m12_lds_bytes;
   int variant;                     // mm_plan_set_variant: 0 = automatic
+  int no_fuse;                     // mm_plan_set_fuse_dct(0): always run the separate clamp + DCT kernel
 
   float* d_window_e;                       // n_fft < 512 embedded in the 512-point kernels: window centred in 512
   int embed;                               // 512 / n_fft for such plans, else 1
@@ -492,13 +509,15 @@ static void interleave_run_groups(float* grp, size_t n_groups) {
 // instruction issue per SIMD (tools/stamps.py), so which wave walks which part of the run table matters:
 // hand the parts out heaviest first to the least loaded SIMD (cost model: ~58 instructions per run +
 // ~8.5 per 4-bin group), heavier parts on the older (= favoured) wave of a SIMD.
-static std::vector<int> balance_parts_over_simds(const mm::MelRuns& r) {
+static std::vector<int> balance_parts_over_simds(const mm::MelRuns& r, const double* extra = nullptr,
+                                                 std::vector<int>* wave_of_part = nullptr) {
   const int n = (int)(r.part.size() / 4);
   std::vector<int> out(r.part.size());
+  if (wave_of_part) { wave_of_part->assign(n, 0); for (int w = 0; w < n; ++w) (*wave_of_part)[w] = w; }
   if (n != 16) return r.part;
   std::vector<std::pair<double, int>> cost(n);
   for (int w = 0; w < n; ++w) {
-    double c = 0;
+    double c = extra ? extra[w] : 0.0;
     for (int i = r.part[w * 4 + 0]; i < r.part[w * 4 + 1]; ++i) c += 58.0 + 8.5 * r.hdr[4 * i + 1];
     cost[w] = {c, w};
   }
@@ -512,6 +531,7 @@ static std::vector<int> balance_parts_over_simds(const mm::MelRuns& r) {
       if (cnt[sd] < 4 && (best < 0 || load[sd] < load[best])) best = sd;
     const int wave = best + 4 * cnt[best];
     std::memcpy(&out[wave * 4], &r.part[cost[i].second * 4], 16);
+    if (wave_of_part) (*wave_of_part)[cost[i].second] = wave;
     load[best] += cost[i].first; ++cnt[best];
   }
   return out;
@@ -566,7 +586,8 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
 
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
-  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0;
+  p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0;
+  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0;
   p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
@@ -695,6 +716,49 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         const size_t lds = nr ? (size_t)(nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tab16.size() * 4 : 0;
         const bool ok = nr && lds <= MM_LM_LDS_MAX && set_s16_attr(MM_LM_LDS_MAX);
         if (ok) { p->s16_nr = nr; p->s16_lds_bytes = lds; }
+      }
+      // staged-sample variant with the DCT fused in: parts 3 / 7 / 11 / 15 of a weighted partition are half
+      // size and their waves compute one frame block's DCT each (10 MFMAs + 20 LDS reads ~ half a mel share)
+      if (p->s16_nr) {
+        const double wts[16] = {1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W};
+        double extra[16];
+        for (int w = 0; w < 16; ++w) extra[w] = wts[w] < 1.0 ? 700.0 : 0.0;     // cost model units: instructions
+        mm::MelSweep swf;
+        const int lt_rows = (cfg->n_mels + 3) & ~3, nk = lt_rows / 4, kbn = (cfg->n_mfcc + 15) / 16;
+        if (mm::build_mel_sweep(*ce, melp, 16, &swf, wts)) {
+          mm::MelRuns rf;
+          mm::build_mel_runs(*ce, swf, 16, &rf);
+          std::vector<float> tabf(rf.hdr.size() + rf.grp.size());
+          std::memcpy(tabf.data(), rf.hdr.data(), rf.hdr.size() * 4);
+          std::memcpy(tabf.data() + rf.hdr.size(), rf.grp.data(), rf.grp.size() * 4);
+          interleave_run_groups(tabf.data() + rf.hdr.size(), rf.grp.size() / 8);
+          std::vector<int> wave_of_part;
+          const std::vector<int> partf = balance_parts_over_simds(rf, extra, &wave_of_part);
+          unsigned long long roles = ~0ull;
+          for (int f = 0; f < 4; ++f) {
+            const int w = wave_of_part[4 * f + 3];
+            roles = (roles & ~(0xFull << (4 * w))) | ((unsigned long long)f << (4 * w));
+          }
+          std::vector<float> dcta((size_t)kbn * nk * 64, 0.0f);
+          for (int kb = 0; kb < kbn; ++kb)
+            for (int s = 0; s < nk; ++s)
+              for (int l = 0; l < 64; ++l) {
+                const int k = 16 * kb + (l & 15), m = 4 * s + (l >> 4);
+                if (k < cfg->n_mfcc && m < cfg->n_mels) dcta[((size_t)kb * nk + s) * 64 + l] = dct[(size_t)k * cfg->n_mels + m];
+              }
+          const size_t tab_end = (size_t)(p->s16_nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tabf.size() * 4;
+          p->s16f_lt_off = (unsigned)align_up(tab_end, 16);
+          p->s16f_dcta_off = p->s16f_lt_off + 2u * (unsigned)lt_rows * 320u;
+          p->s16f_lds_bytes = (size_t)p->s16f_dcta_off + dcta.size() * 4;
+          if (p->s16f_lds_bytes <= MM_LM_LDS_MAX &&
+              upload(&p->d_s16f_tab, tabf.data(), tabf.size() * 4) == MM_OK &&
+              upload(&p->d_s16f_part, partf.data(), partf.size() * 4) == MM_OK &&
+              upload(&p->d_s16f_dcta, dcta.data(), dcta.size() * 4) == MM_OK) {
+            p->s16f_n_runs = (int)(rf.hdr.size() / 4); p->s16f_n_tab16 = (int)(tabf.size() / 4);
+            p->s16f_lt_rows = lt_rows; p->s16f_nk = nk; p->s16f_kb = kbn; p->s16f_roles = roles;
+            p->s16f_ok = 1;
+          }
+        }
       }
       // 12-wave MFMA-mel variant (mm_logmel12m.hip.inc): banded A-operand table, unit lists, LDS budget
       if (p->w16_ok) {
@@ -839,6 +903,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane); (void)hipFree(p->d_window_e);
   (void)hipFree(p->d_rf2k_lane_tab);
   (void)hipFree(p->d_m12_a); (void)hipFree(p->d_m12_dct); (void)hipFree(p->d_zeros);
+  (void)hipFree(p->d_s16f_tab); (void)hipFree(p->d_s16f_dcta); (void)hipFree(p->d_s16f_part);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
   return MM_OK;
@@ -877,6 +942,19 @@ static int choose_kernel(const mm_plan* p, int mode, bool call, const float* d_a
 int mm_plan_kernel_path(const mm_plan* p) {
   if (!p) return MM_ERR_INVALID_ARG;
   return choose_kernel(p, 1, false, nullptr, 0, 0);
+}
+
+int mm_plan_fused_dct(const mm_plan* p) {
+  if (!p) return MM_ERR_INVALID_ARG;
+  const int k = choose_kernel(p, 1, false, nullptr, 0, 0);
+  return !p->no_fuse && ((k == MM_K_M12 && p->m12_fused_dct) || (k == MM_K_W16S && p->s16f_ok)) ? 1 : 0;
+}
+
+int mm_plan_set_fuse_dct(mm_plan* p, int on) {
+  if (!p) return MM_ERR_INVALID_ARG;
+  const int prev = !p->no_fuse;
+  p->no_fuse = on ? 0 : 1;
+  return prev;
 }
 
 int mm_plan_set_variant(mm_plan* p, int variant) {
@@ -958,7 +1036,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.dct_tab = p->d_m12_dct;
     std::memcpy(q.units, p->m12_units, sizeof(q.units));
     std::memcpy(q.n_units, p->m12_nunits, sizeof(q.n_units));
-    o.fused_dct = o.mfcc != nullptr && p->m12_fused_dct;
+    o.fused_dct = o.mfcc != nullptr && p->m12_fused_dct && !p->no_fuse;
     q.out_logmel = (o.fused_dct && p->cfg.top_db < 0.0f) ? nullptr : o.logmel;   // rows only feed the clamp fix-up
     q.out_mfcc = o.fused_dct ? o.mfcc : nullptr;
     q.key_max = o.key_max; q.key_nmin = o.key_nmin;
@@ -984,6 +1062,8 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.wave_part = p->d_sw_part; q.out_logmel = o.logmel; q.clip_key = o.key_max;
     q.out_power = o.power;
     q.dbg = 0;
+    q.out_mfcc = nullptr; q.key_nmin = nullptr; q.dct_a = nullptr; q.n_mfcc = 0; q.dct_nk = q.dct_kb = q.lt_rows = 0;
+    q.lt_off = q.dcta_off = 0; q.dct_roles = ~0ull;
     q.lane_tab = p->d_lane_tab;
     q.preemph = p->cfg.preemph;
     if (q.n_tiles > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
@@ -995,7 +1075,19 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
         const bool pre = p->cfg.preemph != 0.0f;
         const bool odd = p->cfg.hop_length & 1;
         const bool unal = (stride % 4) != 0 || (n_samples % 4) != 0 || (((uintptr_t)d_audio) & 15) != 0;
-        launch_s16(mode, p->s16_nr, pre, odd, unal, dim3((unsigned)grid), p->s16_lds_bytes, st, q);
+        size_t lds = p->s16_lds_bytes;
+        if (mode == 1 && o.mfcc != nullptr && p->s16f_ok && o.key_nmin != nullptr && !p->no_fuse) {
+          // DCT fused in: its own run table (half-size parts for the four DCT waves)
+          o.fused_dct = true;
+          q.mel_tab = (const float4*)p->d_s16f_tab; q.n_runs = p->s16f_n_runs; q.n_tab16 = p->s16f_n_tab16;
+          q.wave_part = p->d_s16f_part;
+          q.out_mfcc = o.mfcc; q.key_nmin = o.key_nmin; q.dct_a = p->d_s16f_dcta; q.n_mfcc = p->cfg.n_mfcc;
+          q.dct_nk = p->s16f_nk; q.dct_kb = p->s16f_kb; q.lt_rows = p->s16f_lt_rows;
+          q.lt_off = p->s16f_lt_off; q.dcta_off = p->s16f_dcta_off; q.dct_roles = p->s16f_roles;
+          if (p->cfg.top_db < 0.0f) q.out_logmel = nullptr;      // the rows only feed the clamp fix-up
+          lds = p->s16f_lds_bytes;
+        }
+        launch_s16(mode, p->s16_nr, pre, odd, unal, dim3((unsigned)grid), lds, st, q);
         HIP_TRY(hipGetLastError());
         return MM_OK;
       }

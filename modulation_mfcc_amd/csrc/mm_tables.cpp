@@ -208,7 +208,7 @@ void build_mel_csr(const mm_config& c, const float* dense, MelCsr* csr) {
 
 // Returns false when the matrix does not have the <= 2 adjacent filters per bin structure
 // (cannot happen for triangular filters with shared edges; checked anyway).
-bool build_mel_sweep(const mm_config& c, const float* dense, int n_waves, MelSweep* out) {
+bool build_mel_sweep(const mm_config& c, const float* dense, int n_waves, MelSweep* out, const double* weights) {
   const int n_mels = c.n_mels, n_bins = c.n_fft / 2 + 1;
   out->wlo.assign(n_bins, 0.0f);
   out->whi.assign(n_bins, 0.0f);
@@ -250,14 +250,17 @@ bool build_mel_sweep(const mm_config& c, const float* dense, int n_waves, MelSwe
   range_of(0, n_mels, &kb_all, &ke_all);
   const double total = (double)(ke_all - kb_all) + 6.0 * n_mels;
   out->part.assign((size_t)n_waves * 4, 0);
+  double wsum = 0.0, wcum = 0.0;
+  for (int w = 0; w < n_waves; ++w) wsum += weights ? weights[w] : 1.0;
   int m = 0;
   for (int w = 0; w < n_waves; ++w) {
+    wcum += weights ? weights[w] : 1.0;
     const int m0 = m;
     int m1 = m0;
     if (w == n_waves - 1) {
       m1 = n_mels;
     } else {
-      const double target = total * (w + 1) / n_waves;
+      const double target = total * wcum / wsum;
       // advance while the cumulative cost of [0, m1) stays below the target
       while (m1 < n_mels) {
         int kb, ke;

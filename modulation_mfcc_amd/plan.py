@@ -196,6 +196,15 @@ class MfccPlan:
     def kernel_path(self):
         return KERNEL_PATHS[self._lib.mm_plan_kernel_path(self._h)]
 
+    @property
+    def fused_dct(self):
+        """True when mfcc() applies the DCT inside the log-mel kernel (plus the clamp fix-up launch)."""
+        return bool(self._lib.mm_plan_fused_dct(self._h))
+
+    def set_fuse_dct(self, on=True):
+        """Allow (default) or forbid the DCT inside the log-mel kernel; returns the previous setting."""
+        return bool(self._lib.mm_plan_set_fuse_dct(self._h, 1 if on else 0))
+
     def set_variant(self, which):
         """Pin a fused-kernel variant (a name from KERNEL_PATHS, its number, or None / 'auto') for the
         calls it can take; returns the previous setting's name."""

@@ -78,7 +78,12 @@ def test_staged_kernel_lengths(n, gpu):
         ref = plan.mfcc(d).cpu().numpy()
         Pr = plan.stft_power(d).cpu().numpy()
     np.testing.assert_array_equal(P, Pr)       # same arithmetic as the direct-load kernel: bit-identical
-    np.testing.assert_array_equal(got, ref)
+    lm, lmr = plan.logmel(d)[0].cpu().numpy(), None
+    with _variant(plan, "w16"):
+        lmr = plan.logmel(d)[0].cpu().numpy()
+    np.testing.assert_array_equal(lm, lmr)     # ... up to the log-mel rows; the staged kernel then applies the DCT
+    for i in range(clips.shape[0]):            # itself (f32 MFMA chain), the direct-load one in dct_clamp_kernel
+        mfcc_close(got[i], ref[i], f"w16s vs w16 n={n} clip {i}")
     for i in range(clips.shape[0]):
         mfcc_close(got[i], O.mfcc(clips[i], O.OracleConfig(**kw)), f"w16s n={n} clip {i}")
 
@@ -102,9 +107,13 @@ def test_staged_kernel_unaligned(n, gpu):
         for i in range(3):
             mfcc_close(got[i], want[i], f"unaligned n={n} pad={pad} lead={lead} clip {i}")
         if (lead + n + pad) % 2 == 0 and lead % 2 == 0 and n >= 2:
+            lm = plan.logmel(view)[0].cpu().numpy()
             with _variant(plan, "w16"):
                 ref = plan.mfcc(view).cpu().numpy()
-            np.testing.assert_array_equal(got, ref)
+                lmr = plan.logmel(view)[0].cpu().numpy()
+            np.testing.assert_array_equal(lm, lmr)
+            for i in range(3):
+                mfcc_close(got[i], ref[i], f"unaligned w16s vs w16 n={n} pad={pad} lead={lead} clip {i}")
 
 
 def test_staged_kernel_large_hop(gpu):

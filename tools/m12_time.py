@@ -10,9 +10,12 @@ dev = torch.device("cuda", 0)
 B, n = 1024, 160000
 g = torch.Generator(device=dev).manual_seed(0)
 audio = 0.05 * torch.randn((B, n), generator=g, device=dev)
+audio += (0.3 * torch.sin(2 * np.pi * 220 * torch.arange(n, device=dev) / 16000.0))[None]
 out = torch.empty((B, 13, 1001), device=dev)
 for v in sys.argv[1:] or ["m12"]:
-    plan.set_variant(v)
+    fuse = not v.endswith("-nofuse")
+    plan.set_variant(v.replace("-nofuse", ""))
+    plan.set_fuse_dct(fuse)
     for _ in range(3): plan.mfcc(audio, out=out)
     torch.cuda.synchronize()
     plan.timing_enable(True)
@@ -20,4 +23,4 @@ for v in sys.argv[1:] or ["m12"]:
     torch.cuda.synchronize()
     plan.timing_enable(False)
     tr = plan.timing_read()
-    print(os.environ.get("MODMFCC_LIB", "product"), v, {k: round(a / c, 4) for k, (a, c) in tr.items()}, flush=True)
+    print(os.environ.get("MODMFCC_LIB", "product"), v, {k: round(a / c, 4) for k, (a, c) in tr.items()}, "sum", round(sum(a / c for a, c in tr.values()), 4), flush=True)
