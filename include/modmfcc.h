@@ -15,7 +15,9 @@
  *   mm_modspec_f32         <- row A8: rFFT over every coefficient's time trajectory
  *                             (build-defined; no reference site)
  *   mm_mfcc_change_f64     <- script/mfcc.py:392-427 (drop c0, Butterworth sosfiltfilt,
- *                             gradient, norm, output filter) -- row N1
+ *                             gradient or Savitzky-Golay derivative, norm, output filter) -- row N1
+ *   mm_stencil_f64         <- get_velocity (script/calc.py:593-650): np.gradient / savgol_filter /
+ *                             findiff derivative of a curve -- row N2
  *   mm_build_window/mel/dct<- scipy.signal.get_window('hann'), librosa.filters.mel,
  *                             scipy.fftpack.dct(type=2, norm='ortho') constant tables
  *
@@ -37,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 100 /* 0.1.0 */
+#define MM_VERSION 110 /* 0.2.0 */
 
 typedef enum mm_status {
   MM_OK = 0,
@@ -162,14 +164,36 @@ int mm_rfft_f32(mm_plan* plan, const float* d_in, int64_t rows, int64_t in_len,
 int mm_modspec_f32(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_t n_frames,
                    float* d_modspec, void* stream);
 
-/* MFCC-change tail (script/mfcc.py:392-427 with diffMethod='grad', outFilter 'iir' low-pass or
- * None): d_mfcc [batch][n_mfcc][n_frames] f32 -> d_change [batch][n_frames] f64.
+/* MFCC-change tail (script/mfcc.py:392-427, outFilter 'iir' low-pass or None): d_mfcc [batch][n_mfcc]
+ * [n_frames] f32 -> d_change [batch][n_frames] f64.  diff_method 0 = np.gradient (diffMethod='grad',
+ * script/mfcc.py:405-407), 1 = savgol_filter(x, 3, 2, deriv=1, mode='interp') (any other diffMethod,
+ * script/mfcc.py:409-412; needs n_frames >= 3).
  * sos1/sos2: HOST pointers to [n_sec][6] Butterworth sections (first / output filter).       */
 int mm_mfcc_change_f64(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_t n_frames,
-                       int32_t remove_first, const double* sos1, int32_t n_sec1,
+                       int32_t remove_first, int32_t diff_method, const double* sos1, int32_t n_sec1,
                        const double* sos2, int32_t n_sec2, double* d_change,
                        void* d_workspace, size_t ws_bytes, void* stream);
 size_t mm_change_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_frames);
+
+/* Derivative transforms of get_velocity (script/calc.py:593-650; row N2) as ONE banded linear operator
+ * along time on float64 rows: interior output i = (sum_k c[k] x[i + off[k]]) / den_c; the n_edge first
+ * outputs = (el[i] . x[0 .. edge_w)) / den_e, the n_edge last ones = (er[i] . x[n - edge_w .. n)) / den_e.
+ * np.gradient (n_c 2, off {-1, +1}, c {-1, 1}, den_c 2h; one edge row {-1, 1}, den_e h) comes out bit for
+ * bit; Savitzky-Golay (mode='interp') and the findiff stencils to float64 round-off.  The host builds the
+ * taps (modulation_mfcc_amd/calc.py: velocity_stencil).  d_x [rows][x_stride] -> d_y [rows][n], n >=
+ * max(2 n_edge, edge_w, spread of off).  Needs no plan. */
+#define MM_ST_MAXW 16
+#define MM_ST_MAXE 8
+typedef struct mm_stencil {
+  int32_t n_c, n_edge, edge_w, reserved;
+  int32_t off[MM_ST_MAXW];
+  double c[MM_ST_MAXW];
+  double el[MM_ST_MAXE][MM_ST_MAXW];
+  double er[MM_ST_MAXE][MM_ST_MAXW];
+  double den_c, den_e;
+} mm_stencil;
+int mm_stencil_f64(const mm_stencil* st, const double* d_x, int64_t rows, int64_t n, int64_t x_stride,
+                   double* d_y, void* stream);
 
 /* Framewise RMS (row N3): librosa.feature.rms(y, frame_length, hop_length, center, pad_mode=
  * 'constant') as called at script/calc.py:331 / script/mfcc.py:247.  d_audio [batch][audio_stride]

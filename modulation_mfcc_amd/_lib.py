@@ -43,6 +43,20 @@ class mm_config(C.Structure):
     ]
 
 
+MM_ST_MAXW, MM_ST_MAXE = 16, 8
+
+
+class mm_stencil(C.Structure):
+    _fields_ = [
+        ("n_c", C.c_int32), ("n_edge", C.c_int32), ("edge_w", C.c_int32), ("reserved", C.c_int32),
+        ("off", C.c_int32 * MM_ST_MAXW),
+        ("c", C.c_double * MM_ST_MAXW),
+        ("el", (C.c_double * MM_ST_MAXW) * MM_ST_MAXE),
+        ("er", (C.c_double * MM_ST_MAXW) * MM_ST_MAXE),
+        ("den_c", C.c_double), ("den_e", C.c_double),
+    ]
+
+
 class MMError(RuntimeError):
     def __init__(self, status, what, detail=""):
         self.status = status
@@ -83,8 +97,9 @@ PROTOTYPES = {
     "mm_stft_power_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mm_rfft_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, C.c_int32, _vp, _vp]),
     "mm_modspec_f32": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
-    "mm_mfcc_change_f64": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int32, _vp, C.c_int32, _vp,
+    "mm_mfcc_change_f64": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int32, C.c_int32, _vp, C.c_int32, _vp,
                                      C.c_int32, _vp, _vp, C.c_size_t, _vp]),
+    "mm_stencil_f64": (C.c_int, [C.POINTER(mm_stencil), _vp, _i64, _i64, _i64, _vp, _vp]),
     "mm_change_workspace_bytes": (C.c_size_t, [_vp, _i64, _i64]),
     "mm_rms_num_frames": (_i64, [_i64, C.c_int32, C.c_int32, C.c_int32]),
     "mm_rms_f32": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
@@ -111,7 +126,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError when the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.mm_version() < 100:
+    if lib.mm_version() < 110:
         raise ImportError("libmodmfcc.so is older than the Python binding; rebuild it")
     _lib = lib
     return lib

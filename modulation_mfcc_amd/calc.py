@@ -12,7 +12,7 @@ from scipy.signal import hilbert, savgol_filter
 
 from .filters import applyFilter
 
-__all__ = ["applyFilter", "get_velocity", "calculate_amplitude_envelope"]
+__all__ = ["applyFilter", "get_velocity", "calculate_amplitude_envelope", "velocity_stencil", "velocity_batch"]
 
 
 def _frame_rms(x, frame_length, hop_length, center):
@@ -83,6 +83,113 @@ def _findiff_first_axis(x, h, order, acc):
     return out / h ** order
 
 
+def _fd_weights(offsets, order):
+    """Finite-difference weights of the ``order``-th derivative on integer ``offsets`` (unit spacing)."""
+    offsets = np.asarray(offsets, dtype=float)
+    m = len(offsets)
+    A = np.vander(offsets, m, increasing=True).T
+    rhs = np.zeros(m)
+    rhs[order] = float(np.prod(np.arange(1, order + 1)))
+    return np.linalg.solve(A, rhs)
+
+
+def velocity_stencil(sr: float, difference: int = 1, method: str = "gradient", width: int = 3,
+                     accOrder: int = 2, polyOrder: int = 2):
+    """The derivative of get_velocity (script/calc.py:593-650) as the banded operator mm_stencil_f64 applies:
+    (stencil dict, passes).  'gradient' is ONE first-derivative stencil applied ``difference`` times, exactly
+    as the reference loops np.gradient.  Raises NotImplementedError when the stencil does not fit the C
+    struct (windows wider than 16 samples, edge zones longer than 8): callers then use the host path."""
+    from . import _lib
+    W, E = _lib.MM_ST_MAXW, _lib.MM_ST_MAXE
+    if method == "gradient":
+        h = 1 / sr      # np.gradient(x, h): (x[i+1] - x[i-1]) / (2 h) inside, first-order differences at the ends
+        return dict(off=[-1, 1], c=[-1.0, 1.0], den_c=2.0 * h, n_edge=1, edge_w=2,
+                    el=[[-1.0, 1.0]], er=[[-1.0, 1.0]], den_e=h), int(difference)
+    if method == "sg":
+        from scipy.signal import savgol_coeffs
+        width, polyOrder, difference = int(width), int(polyOrder), int(difference)
+        half = width // 2
+        if width > W or half > E:
+            raise NotImplementedError("Savitzky-Golay window too wide for the device stencil")
+        conv = savgol_coeffs(width, polyOrder, deriv=difference, delta=1.0)    # taps of scipy's convolve1d
+        c = conv[::-1]                                                         # as a correlation: x[i - half + k]
+        # mode='interp': the first / last half samples come from the polynomial fitted to the first / last
+        # window (scipy.signal._savitzky_golay._fit_edge); linear in the window -> fit unit vectors
+        t = np.arange(width)
+        pc = np.polyfit(t, np.eye(width), polyOrder)                           # [polyOrder + 1, width]
+        for _ in range(difference):
+            pc = pc[:-1] * np.arange(pc.shape[0] - 1, 0, -1)[:, None] if pc.shape[0] > 1 else np.zeros((1, width))
+        el = [[float(np.polyval(pc[:, j], i)) for j in range(width)] for i in range(half)]
+        er = [[float(np.polyval(pc[:, j], width - half + i)) for j in range(width)] for i in range(half)]
+        return dict(off=list(range(-half, half + 1)), c=[float(v) for v in c], den_c=1.0, n_edge=half, edge_w=width,
+                    el=el, er=er, den_e=1.0), 1
+    if method == "finDiff":
+        order, acc = int(difference), int(accOrder)
+        half = (order + 1) // 2 - 1 + acc // 2
+        we = order + acc
+        ew = half - 1 + we if half > 0 else we
+        if 2 * half + 1 > W or ew > W or half > E:
+            raise NotImplementedError("finite-difference stencil too wide for the device stencil")
+        c_off = list(range(-half, half + 1))
+        el = [[0.0] * ew for _ in range(half)]
+        er = [[0.0] * ew for _ in range(half)]
+        for i in range(half):
+            w = _fd_weights(np.arange(0, we), order)             # forward stencil on samples i .. i + we - 1
+            for k in range(we):
+                el[i][i + k] = float(w[k])
+            # output n - half + i: backward stencil on samples i' - (we - 1) .. i', as positions in the last ew
+            w = _fd_weights(np.arange(-(we - 1), 1), order)
+            pos = ew - half + i
+            for k in range(we):
+                er[i][pos - (we - 1) + k] = float(w[k])
+        h = 1 / sr
+        return dict(off=c_off, c=[float(v) for v in _fd_weights(c_off, order)], den_c=h ** order, n_edge=half,
+                    edge_w=ew, el=el, er=er, den_e=h ** order), 1
+    raise ValueError("Méthode inconnue. Utilisez 'gradient', 'sg' ou 'finDiff'.")
+
+
+def velocity_batch(x, sr: float, difference: int = 1, method: str = "gradient", width: int = 3,
+                   accOrder: int = 2, polyOrder: int = 2):
+    """get_velocity along the LAST axis of a float64 CUDA(HIP) tensor [rows, n] (or [n]) on the device
+    (mm_stencil_f64; row N2) -- e.g. on the [B, T] output of MfccPlan.mfcc_change.  'gradient' equals
+    np.gradient(x, 1/sr) bit for bit, 'sg' / 'finDiff' agree with scipy / findiff to float64 round-off."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64):
+        raise TypeError("x must be a float64 CUDA(HIP) tensor")
+    st, passes = velocity_stencil(sr, difference, method, width, accOrder, polyOrder)
+    squeeze = x.dim() == 1
+    x2 = x.unsqueeze(0) if squeeze else x
+    if x2.dim() != 2:
+        raise ValueError("x must be [n] or [rows, n]")
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    rows, n = x2.shape
+    if method == "sg" and n < len(st["c"]):       # scipy.signal.savgol_filter's own check and message
+        raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
+    if n < max(2 * st["n_edge"], st["edge_w"]):
+        raise ValueError("signal too short for the requested finite-difference stencil")
+    cs = _lib.mm_stencil()
+    cs.n_c, cs.n_edge, cs.edge_w = len(st["c"]), st["n_edge"], st["edge_w"]
+    for k, (o, c) in enumerate(zip(st["off"], st["c"])):
+        cs.off[k], cs.c[k] = o, c
+    for i in range(st["n_edge"]):
+        for j in range(st["edge_w"]):
+            cs.el[i][j], cs.er[i][j] = st["el"][i][j], st["er"][i][j]
+    cs.den_c, cs.den_e = st["den_c"], st["den_e"]
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    with torch.cuda.device(x.device):
+        src = x2
+        for _ in range(passes):
+            out = torch.empty((rows, n), dtype=torch.float64, device=x.device)
+            _lib.check(lib.mm_stencil_f64(C.byref(cs), src.data_ptr(), rows, n, src.stride(0), out.data_ptr(), stream),
+                       "mm_stencil_f64")
+            src = out
+    return src[0] if squeeze else src
+
+
 def get_velocity(x: np.ndarray, sr: float, difference: int = 1, method: str = "gradient",
                  width: int = 3, accOrder: int = 2, polyOrder: int = 2):
     """First or second derivative of ``x`` (sampled at ``sr``) -- script/calc.py:593-650.
@@ -90,7 +197,19 @@ def get_velocity(x: np.ndarray, sr: float, difference: int = 1, method: str = "g
     method 'gradient' (np.gradient, repeated ``difference`` times), 'sg' (Savitzky-Golay with
     ``width`` points and polynomial order ``polyOrder``) or 'finDiff' (finite-difference stencils
     of accuracy ``accOrder``).  Unknown methods raise the reference's ValueError.
+
+    A float64 CUDA(HIP) tensor (a curve, or [rows, n] curves along the last axis) is differentiated on
+    the device (``velocity_batch``); numpy input keeps the reference's host arithmetic.
     """
+    if type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False):
+        if method not in ("gradient", "sg", "finDiff"):
+            raise ValueError("Méthode inconnue. Utilisez 'gradient', 'sg' ou 'finDiff'.")
+        try:
+            return velocity_batch(x, sr, difference, method, width, accOrder, polyOrder)
+        except NotImplementedError:
+            import torch
+            y = get_velocity(x.cpu().numpy().T, sr, difference, method, width, accOrder, polyOrder)
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(y).T)).to(x.device)
     if method == "finDiff":
         return _findiff_first_axis(x, 1 / sr, difference, accOrder)
     if method == "sg":

@@ -1325,9 +1325,10 @@ size_t mm_change_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_fram
 }
 
 int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_frames,
-                       int32_t remove_first, const double* sos1, int32_t n_sec1, const double* sos2,
+                       int32_t remove_first, int32_t diff_method, const double* sos1, int32_t n_sec1, const double* sos2,
                        int32_t n_sec2, double* d_change, void* d_ws, size_t ws_bytes, void* stream) {
   if (!p || !d_mfcc || !d_change || !d_ws || batch < 1 || n_frames < 1) return MM_ERR_INVALID_ARG;
+  if (diff_method < 0 || diff_method > 1 || (diff_method == 1 && n_frames < 3)) return MM_ERR_INVALID_ARG;
   if (remove_first < 0 || remove_first >= p->cfg.n_mfcc) return MM_ERR_INVALID_ARG;
   if (batch > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
   SosFilt f1, f2;
@@ -1339,7 +1340,7 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   ChangeParams q;
   q.mfcc = d_mfcc; q.n_frames = n_frames; q.batch = batch; q.n_mfcc = p->cfg.n_mfcc;
   q.first_row = remove_first ? 1 : 0; q.n_rows = q.n_mfcc - q.first_row;
-  q.p1 = f1.padlen; q.p2 = f2.n_sec > 0 ? f2.padlen : 0;
+  q.p1 = f1.padlen; q.p2 = f2.n_sec > 0 ? f2.padlen : 0; q.sg = diff_method;
   q.R = batch * q.n_rows; q.Rp = round64(q.R); q.Bp = round64(batch);
   const int64_t n1 = n_frames + 2 * q.p1, n2 = n_frames + 2 * q.p2;
   q.ws1 = (double*)d_ws; q.ws2 = q.ws1 + n1 * q.Rp; q.out = d_change;
@@ -1359,6 +1360,25 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
     launch_sos_any(f2, q.ws2, n2, q.Bp, st);
   }
   hipLaunchKernelGGL(chg_unpack_kernel, dim3((unsigned)(q.Bp / 64), (unsigned)tblocks), dim3(256), 0, st, q);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
+int mm_stencil_f64(const mm_stencil* st, const double* d_x, int64_t rows, int64_t n, int64_t x_stride, double* d_y,
+                   void* stream) {
+  if (!st || !d_x || !d_y || rows < 1 || n < 1 || x_stride < n) return MM_ERR_INVALID_ARG;
+  if (st->n_c < 1 || st->n_c > MM_ST_MAXW || st->n_edge < 0 || st->n_edge > MM_ST_MAXE || st->edge_w < 0 ||
+      st->edge_w > MM_ST_MAXW || (st->n_edge > 0 && st->edge_w < 1) || st->den_c == 0.0 ||
+      (st->n_edge > 0 && st->den_e == 0.0))
+    return MM_ERR_INVALID_ARG;
+  int lo = 0, hi = 0;
+  for (int k = 0; k < st->n_c; ++k) { lo = std::min(lo, st->off[k]); hi = std::max(hi, st->off[k]); }
+  // every interior output must find its taps inside the row, the edge rows their inputs
+  if (n < 2 * (int64_t)st->n_edge || n < st->edge_w || -lo > st->n_edge || hi > st->n_edge) return MM_ERR_INVALID_ARG;
+  const int64_t total = rows * n;
+  if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(stencil_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *st, d_x,
+                     rows, n, x_stride, d_y);
   HIP_TRY(hipGetLastError());
   return MM_OK;
 }

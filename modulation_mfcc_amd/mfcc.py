@@ -108,7 +108,8 @@ def get_MFCCS_change(audioIn, sigSr, /, *, channelN: int = 0, tStep: float = 0.0
         coeffs_dev = plan.mfcc(torch.from_numpy(y).to(plan.device))
         anchors = _tail.time_anchors(coeffs_dev.shape[2], tStep, winLen)
         change = _tail.mfcc_change_device(plan, coeffs_dev, tStep=tStep, removeFirst=removeFirst,
-                                          filtCutoff=filtCutoff, filtOrd=filtOrd, outFilter=outFilter,
+                                          filtCutoff=filtCutoff, filtOrd=filtOrd, diffMethod=diffMethod,
+                                          outFilter=outFilter,
                                           outFiltType=outFiltType, outFiltCutOff=outFiltCutOff,
                                           outFiltLen=outFiltLen)[0].cpu().numpy()
         return change, anchors

@@ -292,10 +292,11 @@ class MfccPlan:
                                             self._stream()), "mm_modspec_f32")
         return out
 
-    def mfcc_change(self, mfcc, sos1, sos2=None, remove_first=True):
-        """MFCC-change tail on the device (script/mfcc.py:392-427, diffMethod='grad'):
-        [B, n_mfcc, T] float32 -> [B, T] float64.  sos1 / sos2: SOS arrays [n_sec, 6] (host); sos2
-        None applies sos1 again (the reference's outFilter=None branch)."""
+    def mfcc_change(self, mfcc, sos1, sos2=None, remove_first=True, diff_method="grad"):
+        """MFCC-change tail on the device (script/mfcc.py:392-427): [B, n_mfcc, T] float32 -> [B, T]
+        float64.  sos1 / sos2: SOS arrays [n_sec, 6] (host); sos2 None applies sos1 again (the reference's
+        outFilter=None branch).  diff_method 'grad' = np.gradient, anything else = the reference's
+        Savitzky-Golay differentiator savgol_filter(x, 3, 2, deriv=1, mode='interp')."""
         torch = _torch()
         if not (isinstance(mfcc, torch.Tensor) and mfcc.is_cuda and mfcc.dtype == torch.float32
                 and mfcc.dim() == 3 and mfcc.shape[1] == self.cfg.n_mfcc):
@@ -309,10 +310,13 @@ class MfccPlan:
             if T <= 3 * ntaps:   # scipy.signal.sosfiltfilt's own check and message
                 raise ValueError("The length of the input vector x must be greater than padlen, "
                                  f"which is {3 * ntaps}.")
+        sg = 0 if diff_method == "grad" else 1
+        if sg and T < 3:    # scipy.signal.savgol_filter's own check and message
+            raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
         out = torch.empty((B, T), dtype=torch.float64, device=self.device)
         need = int(self._lib.mm_change_workspace_bytes(self._h, B, T))
         ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        _lib.check(self._lib.mm_mfcc_change_f64(self._h, mfcc.data_ptr(), B, T, 1 if remove_first else 0,
+        _lib.check(self._lib.mm_mfcc_change_f64(self._h, mfcc.data_ptr(), B, T, 1 if remove_first else 0, sg,
                                                 s1.ctypes.data, s1.shape[0], s2.ctypes.data, s2.shape[0],
                                                 out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                    "mm_mfcc_change_f64")

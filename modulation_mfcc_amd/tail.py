@@ -5,10 +5,10 @@ after the librosa call.  SURVEY.md 8(f) row N1.
     L2 norm over coefficients / n_coef -> low-pass again (or the caller's output filter)
 
 The filter DESIGN is host arithmetic in the reference (scipy.signal.butter) and stays so.  The
-filtering runs on the device (``mm_mfcc_change_f64``, float64 like scipy) for the reference's default
-branch -- diffMethod='grad' with an IIR output filter or none -- and through the reference's own scipy
-calls (on the MFCC matrix the device returned) for the 'sg' differentiator and the fir / sg output
-filters.
+filtering runs on the device (``mm_mfcc_change_f64``, float64 like scipy) for both differentiators
+(np.gradient, and the Savitzky-Golay derivative every other ``diffMethod`` selects) with an IIR output
+filter or none, and through the reference's own scipy calls (on the MFCC matrix the device returned) for
+the fir / sg OUTPUT filters.
 """
 from __future__ import annotations
 
@@ -30,17 +30,17 @@ def design_lowpass(filtOrd: int, filtCutoff: float, tStep: float) -> np.ndarray:
 
 
 def device_path_applies(diffMethod, outFilter) -> bool:
-    return diffMethod == "grad" and (outFilter is None or outFilter == "iir")
+    return outFilter is None or outFilter == "iir"
 
 
 def mfcc_change_device(plan, mfcc_dev, *, tStep: float, removeFirst=1, filtCutoff=12, filtOrd=6,
-                       outFilter="iir", outFiltType="low", outFiltCutOff=(None,), outFiltLen=6):
+                       diffMethod="grad", outFilter="iir", outFiltType="low", outFiltCutOff=(None,), outFiltLen=6):
     """Device version of ``mfcc_change`` for [B, n_mfcc, T] MFCCs already on the GPU -> [B, T] f64
     tensor.  Raises exactly what the host version raises for bad filter arguments."""
     sos1 = design_lowpass(filtOrd, filtCutoff, tStep)
     sos2 = None if outFilter is None else iir_sos(1 / tStep, cutOff=outFiltCutOff, filtLen=outFiltLen,
                                                   filtType=outFiltType)
-    return plan.mfcc_change(mfcc_dev, sos1, sos2, remove_first=bool(removeFirst))
+    return plan.mfcc_change(mfcc_dev, sos1, sos2, remove_first=bool(removeFirst), diff_method=diffMethod)
 
 
 def mfcc_change(coeffs: np.ndarray, *, tStep: float, removeFirst=1, filtCutoff=12, filtOrd=6,

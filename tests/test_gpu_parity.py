@@ -575,6 +575,10 @@ def test_drop_in_get_MFCCS_change(gpu):
     np.testing.assert_array_equal(T, exp["T"])
     assert tot.dtype == np.float64 and tot.shape == exp["totChange"].shape
     assert np.abs(tot - exp["totChange"]).max() <= 1e-4 * np.abs(exp["totChange"]).max()
+    # the Savitzky-Golay differentiator (any diffMethod other than 'grad', script/mfcc.py:409-412) stays on the device too
+    tot_sg, _ = get_MFCCS_change(y, 10000, tStep=0.005, diffMethod="sg", outFiltCutOff=[12])
+    want_sg = O.mfcc_change_tail(exp["mfcc"].astype(np.float32), tStep=0.005, diffMethod="sg", outFiltCutOff=[12])
+    assert np.abs(tot_sg - want_sg).max() <= 1e-4 * np.abs(want_sg).max()
     # stereo array + channel pick, float64 input (script/mfcc.py:377-380)
     st = np.stack([y.astype(np.float64), np.zeros_like(y, dtype=np.float64)])
     tot2, _ = get_MFCCS_change(st, 10000, channelN=0, tStep=0.005, outFiltCutOff=[12])
@@ -613,9 +617,11 @@ def test_ragged_lengths_fast_and_generic(n, gpu):
     dict(outFiltCutOff=[12]), dict(outFilter=None), dict(removeFirst=0, outFiltCutOff=[20]),
     dict(filtOrd=5, filtCutoff=8, outFiltCutOff=[10], outFiltLen=3),
     dict(outFiltType="band", outFiltCutOff=[2, 20]), dict(outFiltType="high", outFiltCutOff=[3]),
+    dict(diffMethod="sg", outFiltCutOff=[12]), dict(diffMethod="sg", outFilter=None, removeFirst=0),
 ])
 def test_change_tail_on_device(kwargs, gpu):
-    """Row N1: mm_mfcc_change_f64 against scipy's sosfiltfilt / gradient (the reference's tail)."""
+    """Row N1: mm_mfcc_change_f64 against scipy's sosfiltfilt / gradient / savgol_filter (the reference's
+    tail, script/mfcc.py:392-427, both differentiators)."""
     from modulation_mfcc_amd import tail
     kw, y, exp = load_golden("refdefault_am")
     plan = _plan(kw)
@@ -627,6 +633,56 @@ def test_change_tail_on_device(kwargs, gpu):
         # float64 recursion with poles close to the unit circle: fma contraction vs scipy's
         # evaluation order moves results by ~5e-9 relative; tolerance 1e-7 of the curve's maximum
         assert np.abs(got[i] - want).max() <= 1e-7 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(method="gradient", difference=1), dict(method="gradient", difference=2),
+    dict(method="sg", width=3, polyOrder=2, difference=1), dict(method="sg", width=7, polyOrder=3, difference=2),
+    dict(method="sg", width=15, polyOrder=4, difference=1),
+    dict(method="finDiff", difference=1, accOrder=2), dict(method="finDiff", difference=2, accOrder=4),
+    dict(method="finDiff", difference=1, accOrder=6),
+])
+def test_velocity_on_device(kw, gpu):
+    """Row N2: get_velocity (script/calc.py:593-650) on the device -- mm_stencil_f64 on [rows, n] float64
+    curves -- against the reference's own arithmetic on the host: np.gradient bit for bit, scipy's
+    savgol_filter(mode='interp') and the findiff stencils to float64 round-off; ragged lengths down to the
+    shortest the stencil admits, a strided view, a single curve."""
+    import torch
+    from modulation_mfcc_amd import get_velocity, velocity_batch
+    rng = np.random.default_rng(5)
+    sr = 200.0
+    for n in (16, 17, 200, 1001):
+        x = rng.standard_normal((37, n)).cumsum(axis=1)
+        want = np.stack([get_velocity(r, sr, **kw) for r in x])
+        got = velocity_batch(_dev(x, gpu), sr, **kw).cpu().numpy()
+        if kw["method"] == "gradient":
+            np.testing.assert_array_equal(got, want)
+        else:
+            assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    big = torch.zeros((5, 300), dtype=torch.float64, device=gpu)
+    big[:, 3:203] = _dev(x[:5, :200], gpu)
+    got = get_velocity(big[:, 3:203], sr, **kw).cpu().numpy()           # drop-in name, strided rows
+    want = np.stack([get_velocity(r, sr, **kw) for r in x[:5, :200]])
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    one = get_velocity(_dev(x[0], gpu), sr, **kw).cpu().numpy()
+    assert one.shape == (n,) and np.abs(one - get_velocity(x[0], sr, **kw)).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_velocity_of_the_change_curve(gpu):
+    """What the UI does (script/main.py:668-713): the derivative of the MFCC-change curve -- here without
+    leaving the device: mfcc -> change tail -> get_velocity, all clips of a batch at once."""
+    from modulation_mfcc_amd import get_velocity, tail
+    kw, y, exp = load_golden("refdefault_am")
+    plan = _plan(kw)
+    m = plan.mfcc(_dev(np.stack([y, y[::-1].copy()]), gpu))
+    ch = tail.mfcc_change_device(plan, m, tStep=0.005, outFiltCutOff=[12])
+    v = get_velocity(ch, 1 / 0.005, difference=1, method="gradient")
+    hostv = np.stack([get_velocity(c, 1 / 0.005) for c in ch.cpu().numpy()])
+    np.testing.assert_array_equal(v.cpu().numpy(), hostv)
+    with pytest.raises(ValueError, match="Méthode inconnue"):
+        get_velocity(ch, 200.0, method="nope")
+    with pytest.raises(ValueError, match="window_length must be less than or equal"):
+        get_velocity(ch[:, :5], 200.0, method="sg", width=7, polyOrder=2)
 
 
 def test_change_tail_errors(gpu):
