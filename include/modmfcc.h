@@ -16,6 +16,7 @@
  *                             (build-defined; no reference site)
  *   mm_mfcc_change_f64     <- script/mfcc.py:392-427 (drop c0, Butterworth sosfiltfilt,
  *                             gradient or Savitzky-Golay derivative, norm, output filter) -- row N1
+ *   mm_sosfiltfilt_f64     <- applyFilter(filt='iir') (script/mfcc.py:29-135): scipy sosfiltfilt on a batch
  *   mm_stencil_f64         <- get_velocity (script/calc.py:593-650): np.gradient / savgol_filter /
  *                             findiff derivative of a curve -- row N2
  *   mm_build_window/mel/dct<- scipy.signal.get_window('hann'), librosa.filters.mel,
@@ -174,6 +175,14 @@ int mm_mfcc_change_f64(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_
                        const double* sos2, int32_t n_sec2, double* d_change,
                        void* d_workspace, size_t ws_bytes, void* stream);
 size_t mm_change_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_frames);
+
+/* Zero-phase IIR filter of float64 curves: scipy.signal.sosfiltfilt(sos, x) with its defaults (odd
+ * extension by 3 * ntaps samples, sosfilt_zi initial state), i.e. the 'iir' branch of applyFilter
+ * (script/mfcc.py:29-135, script/calc.py:23-129) on a batch.  d_x [rows][x_stride] -> d_y [rows][n];
+ * sos: HOST pointer to [n_sec][6] sections; n must exceed the padding length.  Needs no plan. */
+int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos,
+                       int32_t n_sec, double* d_y, void* d_workspace, size_t ws_bytes, void* stream);
+size_t mm_sosfiltfilt_workspace_bytes(int64_t rows, int64_t n);
 
 /* Derivative transforms of get_velocity (script/calc.py:593-650; row N2) as ONE banded linear operator
  * along time on float64 rows: interior output i = (sum_k c[k] x[i + off[k]]) / den_c; the n_edge first

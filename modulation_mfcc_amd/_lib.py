@@ -99,6 +99,8 @@ PROTOTYPES = {
     "mm_modspec_f32": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "mm_mfcc_change_f64": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int32, C.c_int32, _vp, C.c_int32, _vp,
                                      C.c_int32, _vp, _vp, C.c_size_t, _vp]),
+    "mm_sosfiltfilt_f64": (C.c_int, [_vp, _i64, _i64, _i64, _vp, C.c_int32, _vp, _vp, C.c_size_t, _vp]),
+    "mm_sosfiltfilt_workspace_bytes": (C.c_size_t, [_i64, _i64]),
     "mm_stencil_f64": (C.c_int, [C.POINTER(mm_stencil), _vp, _i64, _i64, _i64, _vp, _vp]),
     "mm_change_workspace_bytes": (C.c_size_t, [_vp, _i64, _i64]),
     "mm_rms_num_frames": (_i64, [_i64, C.c_int32, C.c_int32, C.c_int32]),

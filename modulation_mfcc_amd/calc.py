@@ -8,40 +8,94 @@ the UI to the MFCC-change curve, script/main.py:668-713) and the RMS / Hilbert a
 from __future__ import annotations
 
 import numpy as np
-from scipy.signal import hilbert, savgol_filter
+from scipy.signal import savgol_filter
 
 from .filters import applyFilter
 
-__all__ = ["applyFilter", "get_velocity", "calculate_amplitude_envelope", "velocity_stencil", "velocity_batch"]
+__all__ = ["applyFilter", "get_velocity", "calculate_amplitude_envelope", "velocity_stencil", "velocity_batch",
+           "hilbert_envelope_batch", "amplitude_envelope_batch"]
 
 
-def _frame_rms(x, frame_length, hop_length, center):
-    """librosa.feature.rms(center=..., pad_mode='constant') as called at script/calc.py:331."""
-    x = np.asarray(x, dtype=np.float32)
-    if center:
-        half = frame_length // 2
-        x = np.pad(x, (half, half), mode="constant")
-    n = 1 + (x.shape[0] - frame_length) // hop_length
-    gather = hop_length * np.arange(n)[:, None] + np.arange(frame_length)[None, :]
-    return np.sqrt(np.mean(np.abs(x[gather]) ** 2, axis=-1))
+def _is_device_tensor(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
+def hilbert_envelope_batch(x):
+    """|scipy.signal.hilbert(x)| along the last axis of a CUDA(HIP) tensor ([n] or [B, n], float32 or float64)
+    on the device, in scipy's arithmetic: FFT of length N = len(x) in the input's precision, negative
+    frequencies zeroed / positive ones doubled, inverse FFT, magnitude (script/calc.py:286).
+
+    N is the clip length, an arbitrary integer (160 000 = 2^8 * 5^4 for a 10 s clip): this is the ONE place where
+    the build calls a library transform -- rocFFT through ``torch.fft`` -- instead of its own kernels, whose
+    register radix-16 FFTs cover powers of two up to 8192 (frames, trajectories), not a mixed-radix / Bluestein
+    transform of a whole clip.  The spectrum mask and the magnitude are plain elementwise device work."""
+    import torch
+    if not (_is_device_tensor(x) and x.dtype in (torch.float32, torch.float64)):
+        raise TypeError("x must be a float32 / float64 CUDA(HIP) tensor")
+    n = x.shape[-1]
+    X = torch.fft.fft(x, dim=-1)
+    h = torch.zeros(n, dtype=x.dtype, device=x.device)
+    if n % 2 == 0:
+        h[0] = h[n // 2] = 1
+        h[1:n // 2] = 2
+    else:
+        h[0] = 1
+        h[1:(n + 1) // 2] = 2
+    return torch.fft.ifft(X * h, dim=-1).abs()
+
+
+def amplitude_envelope_batch(x, sr, *, method: str = "RMS", winLen: float = 0.1, hopLen: float = 0.01,
+                             center: bool = True):
+    """The envelope of calculate_amplitude_envelope (script/calc.py:284-343, before its output filter) for a
+    batch of clips on the device: [B, n] (or [n]) CUDA(HIP) tensor -> ([B, n_out], sample rate of the envelope).
+    'RMS' = librosa.feature.rms(frame_length=int(winLen*sr), hop_length=int(hopLen*sr), center, pad_mode=
+    'constant') through mm_rms_f32, 'Hilb' = |hilbert(x)| (hilbert_envelope_batch)."""
+    from .batch import rms_batch
+    if method == "Hilb":
+        return hilbert_envelope_batch(x), 1 / hopLen      # the reference's rate quirk, see below
+    if method == "RMS":
+        import torch
+        xf = x if x.dtype == torch.float32 else x.float()
+        squeeze = xf.dim() == 1
+        env = rms_batch(xf, int(winLen * sr), int(hopLen * sr), center)
+        return (env[0] if squeeze else env), 1 / hopLen
+    if method == "RMSpraat":
+        raise NotImplementedError("method='RMSpraat' calls Praat through parselmouth; not part of this build")
+    raise UnboundLocalError(f"unknown amplitude method {method!r}")
 
 
 def calculate_amplitude_envelope(x, sr, /, *, method: str = "RMS", winLen: float = 0.1,
                                  hopLen: float = 0.01, center: bool = True, outFilter=None,
                                  outFiltType: str = "low", outFiltCutOff=[12], outFiltLen: int = 6,
                                  outFiltPolyOrd: int = 3):
-    """script/calc.py:221-343.  'RMS' and 'Hilb'; 'RMSpraat' needs Praat (out of scope)."""
+    """script/calc.py:221-343.  'RMS' and 'Hilb'; 'RMSpraat' needs Praat (out of scope).
+
+    The envelope is computed on the GPU (framewise RMS: mm_rms_f32; Hilbert: device FFT).  A numpy signal
+    returns numpy arrays like the reference (its output filter, a short per-frame curve, then runs through the
+    reference's own scipy calls on the host); a CUDA(HIP) tensor ([n] or a batch [B, n]) returns device tensors and
+    is filtered on the device too (applyFilter's device branch)."""
     if method == "RMSpraat":
         raise NotImplementedError("method='RMSpraat' calls Praat through parselmouth; not part of this build")
-    if method == "Hilb":
-        env = np.abs(hilbert(x))
-    elif method == "RMS":
-        env = _frame_rms(x, int(winLen * sr), int(hopLen * sr), center).flatten()
-    else:
+    if method not in ("Hilb", "RMS"):
         raise UnboundLocalError(f"unknown amplitude method {method!r}")   # reference: `amp` unbound
+    import torch
+    on_device = _is_device_tensor(x)
+    if on_device:
+        xd = x
+    else:
+        from .plan import _torch  # noqa: F401
+        if not torch.cuda.is_available():
+            raise RuntimeError("modulation_mfcc_amd needs an AMD GPU (gfx950); there is no CPU fallback")
+        xa = np.asarray(x)
+        # librosa.feature.rms / scipy.signal.hilbert keep float32 input in single precision, anything else in double
+        xd = torch.from_numpy(np.ascontiguousarray(xa, dtype=np.float32 if (method == "RMS" or xa.dtype == np.float32)
+                                                   else np.float64)).cuda()
+    env, env_sr = amplitude_envelope_batch(xd, sr, method=method, winLen=winLen, hopLen=hopLen, center=center)
     # the reference tests method != 'hilb' (lower case), so 'Hilb' ALSO gets hop-spaced time stamps
     # and the 1/hopLen rate for its output filter (script/calc.py:333-337); kept as is.
-    times, env_sr = np.arange(len(env)) * hopLen, 1 / hopLen
+    times = np.arange(env.shape[-1]) * hopLen
+    if not on_device:
+        env = env.cpu().numpy()
     if outFilter is not None:
         env = applyFilter(env, env_sr, filt=outFilter, filtType=outFiltType, cutOff=outFiltCutOff,
                           filtLen=outFiltLen, polyOrd=outFiltPolyOrd)

@@ -1364,6 +1364,34 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   return MM_OK;
 }
 
+size_t mm_sosfiltfilt_workspace_bytes(int64_t rows, int64_t n) {
+  if (rows < 1 || n < 1) return 0;
+  return (size_t)(n + 2 * 3 * (2 * MM_MAX_SEC + 1)) * (size_t)round64(rows) * sizeof(double);
+}
+
+int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos, int32_t n_sec,
+                       double* d_y, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d_x || !d_y || !d_ws || rows < 1 || n < 1 || x_stride < n || n_sec < 1) return MM_ERR_INVALID_ARG;
+  SosFilt f;
+  int rc = make_sosfilt(sos, n_sec, &f);
+  if (rc) return rc;
+  if (n <= f.padlen) return MM_ERR_INVALID_ARG;      // scipy: "The length of the input vector x must be greater than padlen"
+  if (ws_bytes < mm_sosfiltfilt_workspace_bytes(rows, n)) return MM_ERR_WORKSPACE;
+  const int64_t Wp = round64(rows), tb = (n + 63) / 64;
+  if (tb > 65535 || Wp / 64 > 0x7FFFFFFF || 2 * (int64_t)f.padlen * Wp / 256 + 1 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  double* ws = (double*)d_ws;
+  hipLaunchKernelGGL(sos_rows_pack_kernel, dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, d_x, rows, n, x_stride,
+                     f.padlen, Wp, ws);
+  hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)f.padlen * Wp + 255) / 256)), dim3(256), 0, st, ws, n,
+                     f.padlen, Wp);
+  launch_sos_any(f, ws, n + 2 * f.padlen, Wp, st);
+  hipLaunchKernelGGL(sos_rows_unpack_kernel, dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, ws, rows, n, f.padlen,
+                     Wp, d_y);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
 int mm_stencil_f64(const mm_stencil* st, const double* d_x, int64_t rows, int64_t n, int64_t x_stride, double* d_y,
                    void* stream) {
   if (!st || !d_x || !d_y || rows < 1 || n < 1 || x_stride < n) return MM_ERR_INVALID_ARG;

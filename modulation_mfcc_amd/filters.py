@@ -56,6 +56,65 @@ def iir_sos(sr, *, cutOff, filtLen=6, filtType="low"):
     return _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
 
 
+def _is_device_tensor(x):
+    return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
+
+
+def sosfiltfilt_batch(x, sos):
+    """scipy.signal.sosfiltfilt(sos, x) along the last axis of a float64 CUDA(HIP) tensor [rows, n] (or [n])
+    on the device (mm_sosfiltfilt_f64): the recursion of applyFilter(filt='iir') for a whole batch of curves."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    if not (_is_device_tensor(x) and x.dtype == torch.float64):
+        raise TypeError("x must be a float64 CUDA(HIP) tensor")
+    squeeze = x.dim() == 1
+    x2 = x.unsqueeze(0) if squeeze else x
+    if x2.dim() != 2:
+        raise ValueError("x must be [n] or [rows, n]")
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    rows, n = x2.shape
+    s = np.ascontiguousarray(np.asarray(sos, dtype=np.float64).reshape(-1, 6))
+    ntaps = 2 * s.shape[0] + 1 - min(int((s[:, 2] == 0).sum()), int((s[:, 5] == 0).sum()))
+    if n <= 3 * ntaps:   # scipy.signal.sosfiltfilt's own check and message
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {3 * ntaps}.")
+    lib = _lib.load()
+    out = torch.empty((rows, n), dtype=torch.float64, device=x.device)
+    ws = torch.empty(int(lib.mm_sosfiltfilt_workspace_bytes(rows, n)), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mm_sosfiltfilt_f64(x2.data_ptr(), rows, n, x2.stride(0), s.ctypes.data, s.shape[0], out.data_ptr(),
+                                          ws.data_ptr(), ws.numel(),
+                                          C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "mm_sosfiltfilt_f64")
+    return out[0] if squeeze else out
+
+
+def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs):
+    """applyFilter for float64 CUDA(HIP) curves ([n] or [rows, n], along the last axis): 'iir' through
+    mm_sosfiltfilt_f64, 'sg' through the banded-operator kernel (mm_stencil_f64); 'fir' has no device kernel
+    and makes the round trip through the host (scipy.signal.filtfilt, as in the reference)."""
+    import torch
+    if x.dtype != torch.float64:
+        x = x.double()                      # scipy filters in float64 whatever the input type
+    if filt == "iir":
+        sos = np.asarray(coeffs) if coeffs is not None else \
+            _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
+        return sosfiltfilt_batch(x, sos)
+    if filt == "sg":
+        if len(cutOff) != 1:
+            raise Exception(_MSG_SG)
+        from .calc import velocity_batch
+        try:
+            return velocity_batch(x, 1.0, 0, "sg", filtLen, 2, polyOrd)
+        except NotImplementedError:
+            pass
+    if filt in ("fir", "sg"):
+        y = applyFilter(x.cpu().numpy(), sr, filt=filt, cutOff=cutOff, filtLen=filtLen,
+                        filtType=kind[:-4], polyOrd=polyOrd, coeffs=coeffs)
+        return torch.from_numpy(np.ascontiguousarray(y)).to(x.device)
+    raise UnboundLocalError(f"applyFilter: unknown filt {filt!r} (expected 'iir', 'fir' or 'sg')")
+
+
 def applyFilter(x, sr, /, *, filt: str = "iir", cutOff=[None], filtLen: int = 6,
                 filtType: str = "low", polyOrd: int = 3, coeffs=None):
     """Zero-phase low / high / band-pass of ``x`` (sampled at ``sr`` Hz).
@@ -70,6 +129,8 @@ def applyFilter(x, sr, /, *, filt: str = "iir", cutOff=[None], filtLen: int = 6,
     Raises the reference's bare ``Exception`` messages for the same bad arguments.
     """
     kind = _validate(filt, cutOff, filtType, sr)
+    if _is_device_tensor(x):       # a batch of curves that lives on the GPU stays there
+        return _apply_filter_device(x, sr, kind, filt=filt, cutOff=cutOff, filtLen=filtLen, polyOrd=polyOrd, coeffs=coeffs)
 
     if filt == "iir":
         sos = np.asarray(coeffs) if coeffs is not None else \

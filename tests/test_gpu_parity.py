@@ -758,6 +758,53 @@ def test_rms_frames_on_device(n, fl, hop, center, gpu):
         np.testing.assert_allclose(got[i], want, rtol=2e-6, atol=1e-7)
 
 
+def test_amplitude_envelope_on_device(gpu):
+    """Row N3, drop-in: calculate_amplitude_envelope (script/calc.py:221-343) computes its envelope on the GPU
+    -- 'RMS' through mm_rms_f32, 'Hilb' through a device FFT of the clip length -- for numpy input (numpy out,
+    the reference's host output filter) and for a batch of clips on the device (device out, device filter);
+    == librosa's rms restatement / scipy.signal.hilbert / scipy's filters."""
+    import scipy.signal
+    from modulation_mfcc_amd import calculate_amplitude_envelope, get_amplitude, applyFilter, sosfiltfilt_batch
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(4000).astype(np.float32)
+    amp, t = calculate_amplitude_envelope(x, 8000.0, method="RMS", winLen=0.05, hopLen=0.01)
+    assert isinstance(amp, np.ndarray) and amp.dtype == np.float32
+    np.testing.assert_allclose(amp, O.rms_envelope(x, 400, 80), rtol=2e-6, atol=1e-7)
+    assert len(t) == len(amp) and t[1] == pytest.approx(0.01)
+    amp2, _ = get_amplitude(x, 8000.0, method="RMS", winLen=0.05, hopLen=0.01, outFilter="iir", outFiltCutOff=[12])
+    want2 = O.apply_filter(O.rms_envelope(x, 400, 80), 100.0, filt="iir", cutOff=[12], filtLen=6, filtType="low", polyOrd=3)
+    np.testing.assert_allclose(amp2, want2, rtol=1e-5, atol=1e-7)
+    # Hilbert envelope: odd / even / non-power-of-two lengths, float32 and float64 like scipy
+    for n, dt in ((4000, np.float32), (4001, np.float32), (160000, np.float32), (12345, np.float64)):
+        xs = rng.standard_normal(n).astype(dt)
+        amp_h, th = calculate_amplitude_envelope(xs, 8000.0, method="Hilb")
+        want = np.abs(scipy.signal.hilbert(xs))
+        assert amp_h.shape == want.shape and amp_h.dtype == want.dtype
+        np.testing.assert_allclose(amp_h, want, rtol=0, atol=(2e-5 if dt == np.float32 else 1e-11) * want.max())
+    # a batch on the device: envelope and IIR / Savitzky-Golay output filters without leaving the GPU
+    xb = rng.standard_normal((5, 16000)).astype(np.float32)
+    for filt, flen in (("iir", 6), ("sg", 7), ("fir", 9)):
+        env, tb = calculate_amplitude_envelope(_dev(xb, gpu), 16000.0, method="RMS", winLen=0.025, hopLen=0.01,
+                                               outFilter=filt, outFiltCutOff=[12], outFiltLen=flen)
+        assert env.is_cuda and env.shape == (5, 101)
+        for i in range(5):
+            want = O.apply_filter(O.rms_envelope(xb[i], 400, 160).astype(np.float64), 100.0, filt=filt, cutOff=[12],
+                                  filtLen=flen, filtType="low", polyOrd=3)
+            np.testing.assert_allclose(env[i].cpu().numpy(), want, rtol=1e-5, atol=1e-7)
+    # mm_sosfiltfilt_f64 against scipy on ragged sizes, band-pass, odd order
+    for rows, n, order, wn, bt in ((1, 22, 6, 0.2, "low"), (37, 1001, 5, 0.1, "low"), (70, 300, 4, [0.05, 0.3], "band"),
+                                   (3, 5000, 8, 0.4, "high")):
+        sos = scipy.signal.butter(order, wn, btype=bt, output="sos")
+        xr = rng.standard_normal((rows, n)).cumsum(axis=1)
+        got = sosfiltfilt_batch(_dev(xr, gpu), sos).cpu().numpy()
+        want = scipy.signal.sosfiltfilt(sos, xr, axis=1)
+        assert np.abs(got - want).max() <= 1e-7 * np.abs(want).max()
+    with pytest.raises(ValueError, match="greater than padlen"):
+        sosfiltfilt_batch(_dev(xr[:, :20], gpu), sos)
+    with pytest.raises(Exception, match="smaller than the half"):
+        applyFilter(_dev(xr, gpu), 100.0, filt="iir", cutOff=[60])
+
+
 def test_plans_with_different_lds_sizes_coexist(gpu):
     """The dynamic-LDS limit is a per-function attribute: creating a plan with a small mel table after
     one with a large table must not break launches of the first (n_mels 128 needs more LDS than 40)."""

