@@ -19,6 +19,8 @@
  *   mm_sosfiltfilt_f64     <- applyFilter(filt='iir') (script/mfcc.py:29-135): scipy sosfiltfilt on a batch
  *   mm_stencil_f64         <- get_velocity (script/calc.py:593-650): np.gradient / savgol_filter /
  *                             findiff derivative of a curve -- row N2
+ *   mm_pcm_decode_f32,
+ *   mm_resample_f32        <- librosa.load(path, sr=sigSr, mono=False) (script/mfcc.py:284,373) -- row N4
  *   mm_build_window/mel/dct<- scipy.signal.get_window('hann'), librosa.filters.mel,
  *                             scipy.fftpack.dct(type=2, norm='ortho') constant tables
  *
@@ -211,6 +213,23 @@ int mm_stencil_f64(const mm_stencil* st, const double* d_x, int64_t rows, int64_
 int64_t mm_rms_num_frames(int64_t n_samples, int32_t frame_length, int32_t hop_length, int32_t center);
 int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t audio_stride,
                int32_t frame_length, int32_t hop_length, int32_t center, float* d_rms, void* stream);
+
+/* Input side (row N4): what librosa.load(path, sr=sigSr, mono=False) does before the hot path
+ * (script/mfcc.py:284,373).
+ * mm_pcm_decode_f32: interleaved little-endian PCM frames (device copy of a WAV data chunk) -> planar
+ *   float32 [channels][out_stride]; fmt 1 = u8, 2 = s16, 3 = packed s24, 4 = s32, 5 = f32, 6 = f64; scaled to
+ *   [-1, 1) as libsndfile does.
+ * mm_resample_f32: rational-ratio (L / M) polyphase FIR sample-rate conversion, zero-phase, n_out =
+ *   ceil(n_in * L / M) as librosa.resample returns; d_taps = DEVICE pointer to the low-pass taps in polyphase
+ *   order [L][taps_per_phase] (taps[p][j] = h[p + j * L], DC gain L), half_len = (len(h) - 1) / 2.  The host
+ *   designs h (modulation_mfcc_amd/audio_io.py: a Kaiser-windowed sinc of soxr-HQ class: pass band to 0.913 of
+ *   the lower Nyquist, > 120 dB stop band); the reference's resampler is soxr_hq, whose coefficients are not
+ *   public API, so outputs agree with it to the quality of both filters, not bit for bit. */
+int mm_pcm_decode_f32(const void* d_raw, int32_t fmt, int32_t channels, int64_t n_frames, float* d_out,
+                      int64_t out_stride, void* stream);
+int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_taps,
+                    int32_t L, int32_t M, int32_t taps_per_phase, int64_t half_len, float* d_y, int64_t n_out,
+                    void* stream);
 
 /* Measurement aid: float4 grid-stride device-to-device copy of n_floats (a multiple of 4; 16-byte
  * aligned pointers) on `stream` -- the practical HBM ceiling bench.py quotes beside the stage-isolated

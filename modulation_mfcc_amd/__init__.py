@@ -10,5 +10,6 @@ from .mfcc import get_MFCCS_change, load_channel, applyFilter, get_amplitude  # 
 from .calc import (get_velocity, calculate_amplitude_envelope, velocity_batch, amplitude_envelope_batch,  # noqa: F401
                    hilbert_envelope_batch)
 from .filters import sosfiltfilt_batch  # noqa: F401
+from .audio_io import load_audio, load_wav, resample_batch  # noqa: F401
 
 __version__ = "0.2.0"

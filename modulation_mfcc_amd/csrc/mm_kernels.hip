@@ -1509,6 +1509,86 @@ int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t s
   return MM_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Input side: what librosa.load(path, sr=sigSr, mono=False) does before the hot
+// path (script/mfcc.py:284,373) -- PCM decode to float32 in [-1, 1) and sample-rate conversion.
+// ------------------------------------------------------------------------------------------
+// interleaved PCM frames -> planar float32 [channels][n]; fmt: 1 = u8, 2 = s16, 3 = s24 (packed), 4 = s32,
+// 5 = f32, 6 = f64 (little endian; scaling as libsndfile / soundfile: s16 / 32768, s24 / 2^23, s32 / 2^31,
+// u8 (x - 128) / 128)
+__global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char* __restrict__ raw, int fmt, int channels,
+                                                         int64_t n, float* __restrict__ out, int64_t out_stride) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * channels) return;
+  const int64_t fr = idx / channels;
+  const int ch = (int)(idx - fr * channels);
+  float v;
+  switch (fmt) {
+    case 1: v = ((float)raw[idx] - 128.0f) * (1.0f / 128.0f); break;
+    case 2: { const short q = (short)((unsigned)raw[2 * idx] | ((unsigned)raw[2 * idx + 1] << 8)); v = (float)q * (1.0f / 32768.0f); break; }
+    case 3: { int q = (int)((unsigned)raw[3 * idx] | ((unsigned)raw[3 * idx + 1] << 8) | ((unsigned)raw[3 * idx + 2] << 16));
+              q = (q << 8) >> 8; v = (float)q * (1.0f / 8388608.0f); break; }
+    case 4: { const int q = (int)((unsigned)raw[4 * idx] | ((unsigned)raw[4 * idx + 1] << 8) | ((unsigned)raw[4 * idx + 2] << 16) |
+                                  ((unsigned)raw[4 * idx + 3] << 24));
+              v = (float)((double)q * (1.0 / 2147483648.0)); break; }
+    case 5: { unsigned u = (unsigned)raw[4 * idx] | ((unsigned)raw[4 * idx + 1] << 8) | ((unsigned)raw[4 * idx + 2] << 16) |
+                           ((unsigned)raw[4 * idx + 3] << 24);
+              v = __uint_as_float(u); break; }
+    default: { unsigned long long u = 0;
+               for (int b = 0; b < 8; ++b) u |= (unsigned long long)raw[8 * idx + b] << (8 * b);
+               v = (float)__longlong_as_double((long long)u); break; }
+  }
+  out[(int64_t)ch * out_stride + fr] = v;
+}
+
+int mm_pcm_decode_f32(const void* d_raw, int32_t fmt, int32_t channels, int64_t n_frames, float* d_out, int64_t out_stride,
+                      void* stream) {
+  if (!d_raw || !d_out || fmt < 1 || fmt > 6 || channels < 1 || n_frames < 1 || out_stride < n_frames) return MM_ERR_INVALID_ARG;
+  const int64_t total = n_frames * channels;
+  if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(pcm_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)d_raw, fmt, channels, n_frames, d_out, out_stride);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
+// Rational-ratio polyphase FIR resampler: y[m] = sum_i x[i] h[m M - i L + c], c = (len(h) - 1) / 2, zero
+// signal outside the clip -- upfirdn with the filter delay removed, n_out = ceil(n L / M) (what
+// scipy.signal.resample_poly and librosa.resample return).  hp = the taps in polyphase order [L][tpp]:
+// hp[p][j] = h[p + j L]; one thread per output sample, float64 accumulation.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int64_t rows, int64_t n_in,
+                                                       int64_t in_stride, const float* __restrict__ hp, int L, int M,
+                                                       int tpp, int64_t c, int64_t n_out, float* __restrict__ y) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * n_out) return;
+  const int64_t r = idx / n_out, m = idx - r * n_out;
+  const int64_t t = m * M + c;
+  const int64_t ih = t / L;
+  const int ph = (int)(t - ih * L);
+  const float* xr = x + r * in_stride;
+  const float* h = hp + (int64_t)ph * tpp;
+  double acc = 0.0;
+  for (int j = 0; j < tpp; ++j) {
+    const int64_t i = ih - j;
+    if (i >= 0 && i < n_in) acc = fma((double)h[j], (double)xr[i], acc);
+  }
+  y[r * n_out + m] = (float)acc;
+}
+
+int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_taps, int32_t L, int32_t M,
+                    int32_t taps_per_phase, int64_t half_len, float* d_y, int64_t n_out, void* stream) {
+  if (!d_x || !d_taps || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || L < 1 || M < 1 || taps_per_phase < 1 ||
+      half_len < 0 || n_out < 1)
+    return MM_ERR_INVALID_ARG;
+  if (n_out != (n_in * L + M - 1) / M) return MM_ERR_INVALID_ARG;
+  const int64_t total = rows * n_out;
+  if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, rows, n_in,
+                     x_stride, d_taps, L, M, taps_per_phase, half_len, n_out, d_y);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
 // Measurement aid (bench.py): float4 grid-stride device-to-device copy on the caller's stream -- the
 // practical HBM ceiling the stage-isolated rFFT figure is compared with (MI355X_MICROARCH.md quotes
 // 6.29 TB/s for this shape of kernel).  n_floats must be a multiple of 4, pointers 16-byte aligned.

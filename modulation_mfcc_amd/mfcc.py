@@ -6,9 +6,9 @@ behaviour as the reference (script/mfcc.py:29-39, 262-264, 291-311), so the Qt U
 get_MFCCS_change, load_channel``.  The librosa.feature.mfcc call at script/mfcc.py:387 is replaced
 by the HIP path (``MfccPlan.mfcc`` -> libmodmfcc.so); there is no CPU fallback for it.
 
-Host side, as in the reference: filter DESIGN (scipy.signal.butter / firwin) and the 'fir' / 'sg'
-branches of applyFilter (they are scipy calls in the reference too).  The MFCC-change tail
-(script/mfcc.py:392-427) is in ``tail.py``.
+Host side, as in the reference: filter DESIGN (scipy.signal.butter / firwin) and the 'fir' branch of
+applyFilter (a scipy call in the reference too).  The MFCC-change tail (script/mfcc.py:392-427) is in
+``tail.py``, the input side (WAVE decode + resampling, script/mfcc.py:284,373) in ``audio_io.py``.
 """
 from __future__ import annotations
 
@@ -23,34 +23,19 @@ __all__ = ["applyFilter", "get_amplitude", "load_channel", "get_MFCCS_change", "
 applyFilter = _filters.applyFilter
 
 
-def _decode_wav(path):
-    """PCM / float WAV -> (float32 [ch, n] in [-1, 1), sr).  Host-side input decoding (row N4)."""
-    from scipy.io import wavfile
-    sr, data = wavfile.read(path)
-    if data.dtype == np.uint8:
-        x = (data.astype(np.float32) - 128.0) / 128.0
-    elif np.issubdtype(data.dtype, np.integer):
-        x = data.astype(np.float32) / float(2 ** (8 * data.dtype.itemsize - 1))
-    else:
-        x = data.astype(np.float32)
-    x = x.T if x.ndim == 2 else x
-    return np.ascontiguousarray(x), float(sr)
+def _load_audio_device(path, sr):
+    """librosa.load(path, sr=sr, mono=False) (script/mfcc.py:284,373) for WAVE files, on the device: float32
+    CUDA(HIP) tensor, [n] for a mono file and [channels, n] otherwise -- RIFF header parsed on the host, PCM
+    decode and sample-rate conversion by the kernels of row N4 (modulation_mfcc_amd/audio_io.py, which also
+    states how the resampler relates to librosa's soxr_hq)."""
+    from .audio_io import load_audio
+    x = load_audio(path, sr)
+    return x[0] if x.shape[0] == 1 else x
 
 
 def _load_audio(path, sr):
-    """Stand-in for librosa.load(path, sr=sr, mono=False) (script/mfcc.py:284,373).
-
-    librosa resamples with soxr_hq, which is not available offline; this uses a polyphase FIR
-    (scipy.signal.resample_poly), so path-string inputs that need resampling match the reference
-    only approximately.  Arrays passed directly (the batch API, the tests) are unaffected.
-    """
-    x, file_sr = _decode_wav(path)
-    if sr is not None and float(sr) != file_sr:
-        from fractions import Fraction
-        from scipy.signal import resample_poly
-        fr = Fraction(float(sr) / file_sr).limit_denominator(1000)
-        x = resample_poly(x, fr.numerator, fr.denominator, axis=-1).astype(np.float32)
-    return x
+    """Same, as the numpy array the reference's callers get."""
+    return _load_audio_device(path, sr).cpu().numpy()
 
 
 def load_channel(file_path: str, signal_sample_rate: float = 10_000, channel_nb: int = 0):
@@ -93,19 +78,22 @@ def get_MFCCS_change(audioIn, sigSr, /, *, channelN: int = 0, tStep: float = 0.0
     change curve and the time anchor of every frame, as the reference does.  The MFCCs come from
     the HIP kernels (float32 arithmetic; arrays of any float dtype are cast to float32).
     """
-    signal = _load_audio(audioIn, sigSr) if isinstance(audioIn, str) else audioIn
-    if np.ndim(signal) > 1:
+    signal = _load_audio_device(audioIn, sigSr) if isinstance(audioIn, str) else audioIn   # a path never leaves the GPU
+    if signal.ndim > 1:
         signal = signal[channelN, :]
 
     cfg = MfccConfig.from_reference_call(sigSr, tStep=tStep, winLen=winLen, n_mfcc=n_mfcc,
                                          n_fft=n_fft, minFreq=minFreq, maxFreq=maxFreq)
     if _tail.device_path_applies(diffMethod, outFilter):
         import torch
-        y = np.ascontiguousarray(np.asarray(signal), dtype=np.float32)
-        if y.ndim != 1:
-            raise ValueError("expected a 1-D signal")
         plan = get_plan(cfg)
-        coeffs_dev = plan.mfcc(torch.from_numpy(y).to(plan.device))
+        if isinstance(signal, torch.Tensor):
+            y = signal.to(device=plan.device, dtype=torch.float32)
+        else:
+            y = torch.from_numpy(np.ascontiguousarray(np.asarray(signal), dtype=np.float32)).to(plan.device)
+        if y.dim() != 1:
+            raise ValueError("expected a 1-D signal")
+        coeffs_dev = plan.mfcc(y)
         anchors = _tail.time_anchors(coeffs_dev.shape[2], tStep, winLen)
         change = _tail.mfcc_change_device(plan, coeffs_dev, tStep=tStep, removeFirst=removeFirst,
                                           filtCutoff=filtCutoff, filtOrd=filtOrd, diffMethod=diffMethod,
@@ -113,7 +101,7 @@ def get_MFCCS_change(audioIn, sigSr, /, *, channelN: int = 0, tStep: float = 0.0
                                           outFiltType=outFiltType, outFiltCutOff=outFiltCutOff,
                                           outFiltLen=outFiltLen)[0].cpu().numpy()
         return change, anchors
-    coeffs = mfcc_array(signal, cfg)
+    coeffs = mfcc_array(signal.cpu().numpy() if hasattr(signal, "is_cuda") else signal, cfg)
     anchors = _tail.time_anchors(coeffs.shape[1], tStep, winLen)
     change = _tail.mfcc_change(coeffs, tStep=tStep, removeFirst=removeFirst, filtCutoff=filtCutoff,
                                filtOrd=filtOrd, diffMethod=diffMethod, outFilter=outFilter,

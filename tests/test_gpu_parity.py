@@ -805,6 +805,70 @@ def test_amplitude_envelope_on_device(gpu):
         applyFilter(_dev(xr, gpu), 100.0, filt="iir", cutOff=[60])
 
 
+def test_load_and_resample_on_device(tmp_path, gpu):
+    """Row N4: WAVE decode and sample-rate conversion on the device (mm_pcm_decode_f32, mm_resample_f32) --
+    every encoding against scipy.io.wavfile + libsndfile's scaling, the resampler against scipy's polyphase
+    arithmetic with the SAME taps (kernel parity; the taps' quality is checked in tests/test_host.py), the
+    drop-in load_channel / get_MFCCS_change on a path (the form the UI uses, script/main.py:750,1049)."""
+    import scipy.io.wavfile
+    import scipy.signal
+    import torch
+    from test_host import _write_wav
+    from modulation_mfcc_amd import get_MFCCS_change, load_channel, load_audio, load_wav, resample_batch
+    from modulation_mfcc_amd.audio_io import design_taps, resample_ratio
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.9, 0.9, (30001, 2))
+    for kind, bits, ext in (("int", 8, False), ("int", 16, False), ("int", 24, False), ("int", 32, False),
+                            ("float", 32, False), ("float", 64, False), ("int", 24, True)):
+        for ch in (1, 2):
+            p = str(tmp_path / f"d_{kind}{bits}_{ext}_{ch}.wav")
+            _write_wav(p, x[:, :ch], 22050, kind, bits, ext)
+            got, sr = load_wav(p)
+            assert sr == 22050.0 and got.shape == (ch, 30001) and got.dtype == torch.float32
+            if kind == "float":
+                want = x[:, :ch].astype(np.float32 if bits == 32 else np.float64).astype(np.float32)
+            elif bits == 8:
+                want = ((np.clip(np.round(x[:, :ch] * 128 + 128), 0, 255) - 128) / 128).astype(np.float32)
+            else:
+                q = np.clip(np.round(x[:, :ch] * (1 << (bits - 1))), -(1 << (bits - 1)), (1 << (bits - 1)) - 1)
+                want = (q / float(1 << (bits - 1))).astype(np.float32)
+            np.testing.assert_array_equal(got.cpu().numpy(), want.T)
+            if not ext and not (kind == "int" and bits == 24):
+                _, ref = scipy.io.wavfile.read(p)           # same samples as an independent reader sees
+                assert ref.reshape(30001, -1).shape[1] == ch
+    # resampler kernel == upfirdn with the same taps (float64 accumulation on both sides)
+    xs = rng.standard_normal((3, 20000)).astype(np.float32)
+    for sr_in, sr_out in ((48000, 16000), (44100, 16000), (44100, 10000), (16000, 10000), (8000, 16000), (16000, 16000)):
+        got = resample_batch(_dev(xs, gpu), sr_in, sr_out).cpu().numpy()
+        L, M = resample_ratio(sr_in, sr_out)
+        if L == M:
+            np.testing.assert_array_equal(got, xs)
+            continue
+        h, half = design_taps(L, M)
+        want = scipy.signal.resample_poly(xs.astype(np.float64), L, M, axis=1, window=h.astype(np.float32).astype(np.float64) / L)
+        assert got.shape == want.shape == (3, -(-20000 * L // M))
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    # drop-in: a path at the file's own rate gives exactly what the array gives; a resampled path is close to it
+    kw, y, exp = load_golden("refdefault_am")
+    p = str(tmp_path / "clip.wav")
+    _write_wav(p, np.stack([y, 0.5 * y], axis=1), 10000, "float", 32)
+    ch = load_channel(p, 10000)
+    assert isinstance(ch, np.ndarray) and ch.shape == (2, y.shape[0])
+    np.testing.assert_array_equal(ch[0], y)
+    a, Ta = get_MFCCS_change(p, 10000, channelN=0, tStep=0.005, outFiltCutOff=[12])
+    b, Tb = get_MFCCS_change(y, 10000, tStep=0.005, outFiltCutOff=[12])
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(Ta, Tb)
+    p2 = str(tmp_path / "clip48.wav")
+    t = np.arange(48000 * 2) / 48000.0
+    z = 0.3 * np.sin(2 * np.pi * 220 * t) * (1 + 0.5 * np.sin(2 * np.pi * 4 * t)) + 0.01 * rng.standard_normal(t.size)
+    _write_wav(p2, z, 48000, "int", 16)
+    lo = load_audio(p2, 16000)
+    assert lo.shape == (1, 32000)
+    c, _ = get_MFCCS_change(p2, 16000, tStep=0.01, outFiltCutOff=[12])
+    assert c.shape == (201,) and np.isfinite(c).all()
+
+
 def test_plans_with_different_lds_sizes_coexist(gpu):
     """The dynamic-LDS limit is a per-function attribute: creating a plan with a small mel table after
     one with a large table must not break launches of the first (n_mels 128 needs more LDS than 40)."""

@@ -91,3 +91,88 @@ def test_amplitude_envelope_needs_the_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             calculate_amplitude_envelope(x, 8000.0, method="RMS", winLen=0.05, hopLen=0.01)
+
+
+def _write_wav(path, data, sr, kind="int", bits=16, extensible=False):
+    """Minimal RIFF/WAVE writer for the tests: data [n, ch] float in [-1, 1)."""
+    import struct
+    data = np.atleast_2d(np.asarray(data, dtype=np.float64).T).T
+    n, ch = data.shape
+    if kind == "float":
+        raw = data.astype("<f4" if bits == 32 else "<f8").tobytes()
+        tag = 3
+    elif bits == 8:
+        raw = np.clip(np.round(data * 128 + 128), 0, 255).astype(np.uint8).tobytes()
+        tag = 1
+    elif bits == 24:
+        q = np.clip(np.round(data * (1 << 23)), -(1 << 23), (1 << 23) - 1).astype("<i4")
+        raw = q.reshape(-1, 1).view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+        tag = 1
+    else:
+        q = np.clip(np.round(data * (1 << (bits - 1))), -(1 << (bits - 1)), (1 << (bits - 1)) - 1)
+        raw = q.astype("<i2" if bits == 16 else "<i4").tobytes()
+        tag = 1
+    align = ch * bits // 8
+    if extensible:
+        guid = struct.pack("<H", tag) + bytes.fromhex("000000001000800000aa00389b71")
+        fmt = struct.pack("<HHIIHHHHI", 0xFFFE, ch, sr, sr * align, align, bits, 22, bits, 0) + guid
+    else:
+        fmt = struct.pack("<HHIIHH", tag, ch, sr, sr * align, align, bits)
+    junk = b"LIST" + struct.pack("<I", 5) + b"abcde\0"          # an odd-sized chunk before the data
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + junk + b"data" + struct.pack("<I", len(raw)) + raw
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    return raw
+
+
+def test_wav_header_parser(tmp_path):
+    """Row N4, host part: the RIFF/WAVE parser (modulation_mfcc_amd/audio_io.py) on PCM 8 / 16 / 24 / 32, float
+    32 / 64, WAVE_FORMAT_EXTENSIBLE, an odd-sized chunk in front of the data, mono and stereo."""
+    from modulation_mfcc_amd.audio_io import read_wav_header
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.9, 0.9, (1000, 2))
+    for kind, bits, ext, fmt in (("int", 8, False, 1), ("int", 16, False, 2), ("int", 24, False, 3), ("int", 32, False, 4),
+                                 ("float", 32, False, 5), ("float", 64, False, 6), ("int", 24, True, 3), ("float", 32, True, 5)):
+        for ch in (1, 2):
+            p = str(tmp_path / f"t_{kind}{bits}_{ext}_{ch}.wav")
+            raw = _write_wav(p, x[:, :ch], 22050, kind, bits, ext)
+            h = read_wav_header(p)
+            assert (h["sr"], h["channels"], h["bits"], h["kind"], h["fmt"]) == (22050.0, ch, bits, kind, fmt)
+            assert h["n_frames"] == 1000 and h["data_bytes"] == len(raw)
+            assert open(p, "rb").read()[h["data_offset"]:h["data_offset"] + 16] == raw[:16]
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"RIFF\x04\x00\x00\x00WAVX")
+    with pytest.raises(ValueError, match="not a RIFF/WAVE"):
+        read_wav_header(str(bad))
+
+
+@pytest.mark.parametrize("sr_in,sr_out", [(48000, 16000), (44100, 16000), (44100, 10000), (16000, 10000), (8000, 16000)])
+def test_resampler_quality(sr_in, sr_out):
+    """Row N4: the low-pass the device resampler applies meets the soxr-HQ-class specification it is designed
+    to (pass band to 0.913 of the lower Nyquist within 1e-4 dB, >= 120 dB from the Nyquist up), and polyphase
+    conversion with it reproduces an in-band multi-tone signal -- sampled analytically at the new rate -- to
+    better than 100 dB, while a tone above the new Nyquist disappears.  (The kernel itself is compared with
+    this same arithmetic on the GPU: tests/test_gpu_parity.py::test_load_and_resample_on_device.)"""
+    from modulation_mfcc_amd.audio_io import design_taps, resample_ratio
+    L, M = resample_ratio(sr_in, sr_out)
+    assert L * sr_in == M * sr_out
+    h, half = design_taps(L, M)
+    assert len(h) == 2 * half + 1 and abs(h.sum() - L) < 1e-9 and np.allclose(h, h[::-1])
+    H = np.abs(np.fft.rfft(h, 1 << 20)) / L
+    f = np.fft.rfftfreq(1 << 20)
+    fN = 0.5 / max(L, M)
+    pb, sb = H[f <= 0.913 * fN], H[f >= fN]
+    assert 20 * np.log10(pb.max() / pb.min()) < 1e-4 and 20 * np.log10(sb.max()) < -120.0
+    n = 6000
+    t_in, n_out = np.arange(n) / sr_in, -(-n * L // M)
+    t_out = np.arange(n_out) / sr_out
+    f_lo = min(sr_in, sr_out) / 2
+    tones = [0.05 * f_lo, 0.37 * f_lo, 0.9 * f_lo]
+    sig = lambda t: sum(np.sin(2 * np.pi * fr * t + 0.3 * i) for i, fr in enumerate(tones))   # noqa: E731
+    y = scipy.signal.resample_poly(sig(t_in), L, M, window=h / L)      # scipy multiplies explicit taps by `up`
+    mid = slice(half // M + 50, n_out - half // M - 50)                # away from the zero-padded clip ends
+    err = np.abs(y - sig(t_out))[mid].max()
+    assert 20 * np.log10(err / 3.0) < -100.0
+    if sr_out < sr_in:
+        alias = scipy.signal.resample_poly(np.sin(2 * np.pi * 1.2 * f_lo * t_in), L, M, window=h / L)
+        assert 20 * np.log10(np.abs(alias[mid]).max()) < -115.0
