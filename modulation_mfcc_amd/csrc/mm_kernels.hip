@@ -873,6 +873,12 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         p->k2_ok = 1;
     }
   }
+  if (hipFuncSetAttribute((const void*)rfft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) !=
+      hipSuccess) {
+    g_hip_err = "hipFuncSetAttribute(rfft_generic_kernel) failed";
+    mm_plan_destroy(p);
+    return MM_ERR_HIP;
+  }
   {
     const std::vector<float> lt = wpf_lane_table(4, nullptr, tw.data());
     if (upload(&p->d_rf2k_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
@@ -1061,7 +1067,6 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.window = p->embed > 1 ? p->d_window_e : p->d_window; q.tw = p->d_tw; q.mel_tab = (const float4*)p->d_sw_tab; q.n_runs = p->sw_n_runs; q.n_tab16 = p->sw_n_tab16;
     q.wave_part = p->d_sw_part; q.out_logmel = o.logmel; q.clip_key = o.key_max;
     q.out_power = o.power;
-    q.dbg = 0;
     q.out_mfcc = nullptr; q.key_nmin = nullptr; q.dct_a = nullptr; q.n_mfcc = 0; q.dct_nk = q.dct_kb = q.lt_rows = 0;
     q.lt_off = q.dcta_off = 0; q.dct_roles = ~0ull;
     q.lane_tab = p->d_lane_tab;
@@ -1246,14 +1251,7 @@ static int launch_rfft(mm_plan* p, const float* d_in, int64_t rows, int64_t in_l
   const int nc = n / 2;
   const int64_t grid = (rows + 4 * q.rows_per_wave - 1) / (4 * q.rows_per_wave);
   if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  if ((size_t)4 * nc * 8 > 65536) {   // n = 8192 needs 128 KB of dynamic LDS
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_TRY(hipFuncSetAttribute((const void*)rfft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  163840));
-      attr_set = true;
-    }
-  }
+  // (n = 8192 needs 128 KB of dynamic LDS: the function attribute is raised once, in mm_plan_create)
   hipLaunchKernelGGL(rfft_generic_kernel, dim3((unsigned)grid), dim3(256), (size_t)4 * nc * 8, st, q);
   HIP_TRY(hipGetLastError());
   return MM_OK;

@@ -1,8 +1,5 @@
 #!/bin/bash
-# dev helper (GPU box): fused-kernel time of the n_fft = 512 variants on the same box, interleaved
-P='import json,sys; d=json.loads(sys.stdin.read()); print(d["config"]["kernel_path"], d["kernels_ms"]["logmel"], "ms_per_step", round(d["ms_per_step"],4))'
-for i in 1 2 3; do
-  for mp in 0 2; do
-    MM_PATH=$mp python bench.py --no-cpu --steps 20 --warmup 3 2>/dev/null | python -c "$P"
-  done
-done
+# dev helper (GPU box): same-box A/B of the n_fft = 512 kernel variants, interleaved, in ONE process per
+# call (tools/m12_time.py pins variants through mm_plan_set_variant / mm_plan_set_fuse_dct; the library
+# reads no environment variable).  usage: tools/ab.sh [variants...]   e.g. tools/ab.sh w16s w16s-nofuse m12
+python tools/m12_time.py "${@:-w16s w16s-nofuse m12 w16s w16s-nofuse m12}"

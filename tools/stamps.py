@@ -1,7 +1,7 @@
-"""dev helper: build with -DMM_STAMP, run the fused kernel, print per-section cycle totals of workgroup 0.
+"""dev helper: build a side copy with -DMM_STAMP (tools/build_ru.sh style, -o ../libmodmfcc_stamp.so) and point MODMFCC_LIB at it; runs the fused kernel, print per-section cycle totals of workgroup 0.
 Sections: 0 window (+wait for samples)  1 DFT-16 #1  2 twiddles  3 exchange + DFT-16 #2  4 split + power rows
 5 prefetch issue  6 barrier A->B  7 phase B  8 barrier B->A  9 loop top  10 exchange (then 3 = DFT-16 #2 alone)
-w16s (MM_PATH=4): 11 staging loads issued, 0 S reads + window, 5 staging store (after barrier A->B)"""
+w16s: 11 staging loads issued, 0 S reads + window, 5 staging store (after barrier A->B)"""
 import sys, ctypes, subprocess, os
 sys.path.insert(0, '.')
 import numpy as np, torch
