@@ -135,7 +135,11 @@ def _torch():
 
 
 class MfccPlan:
-    """Owns one ``mm_plan`` on the current CUDA(HIP) device.  Raises when no GPU is present."""
+    """Owns one ``mm_plan`` on the current CUDA(HIP) device.  Raises when no GPU is present.
+
+    One plan = one stream at a time: the log-mel workspace (``workspace()``) is owned by the plan and reused by
+    every ``mfcc`` call, so concurrent calls on different streams need one plan each (plans are cheap: a few
+    hundred KB of constant tables)."""
 
     def __init__(self, cfg: MfccConfig, device=None):
         torch = _torch()
@@ -183,7 +187,20 @@ class MfccPlan:
             audio = audio.contiguous()
         if audio.shape[1] < 1:
             raise ValueError("empty audio")
+        if audio.device != self.device:
+            raise ValueError(f"audio is on {audio.device}, the plan on {self.device}")
         return audio
+
+    def _check_out(self, out, shape, dtype, what):
+        """A caller-provided output must be exactly what the kernel writes: its data_ptr() goes to the C ABI
+        unchecked otherwise (a short or strided tensor would be an out-of-bounds device write)."""
+        torch = _torch()
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.device == self.device):
+            raise TypeError(f"{what}: out must be a tensor on {self.device}")
+        if out.dtype != dtype or tuple(out.shape) != tuple(shape) or not out.is_contiguous():
+            raise ValueError(f"{what}: out must be a contiguous {dtype} tensor of shape {tuple(shape)}, "
+                             f"got {out.dtype} {tuple(out.shape)} (contiguous: {out.is_contiguous()})")
+        return out
 
     def workspace(self, batch, n_samples):
         torch = _torch()
@@ -231,10 +248,13 @@ class MfccPlan:
         T = self.cfg.num_frames(n)
         if out is None:
             out = torch.empty((B, self.cfg.n_mfcc, T), dtype=torch.float32, device=self.device)
+        else:
+            self._check_out(out, (B, self.cfg.n_mfcc, T), torch.float32, "mfcc")
         ws = self.workspace(B, n)
-        _lib.check(self._lib.mm_mfcc_f32(self._h, audio.data_ptr(), B, n, audio.stride(0),
-                                         out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
-                   "mm_mfcc_f32")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mm_mfcc_f32(self._h, audio.data_ptr(), B, n, audio.stride(0),
+                                             out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                       "mm_mfcc_f32")
         return out
 
     def logmel(self, audio):
@@ -270,8 +290,12 @@ class MfccPlan:
         if rows.stride(1) != 1:
             rows = rows.contiguous()
         R, L = rows.shape
+        if rows.device != self.device:
+            raise ValueError(f"rows is on {rows.device}, the plan on {self.device}")
         if out is None:
             out = torch.empty((R, n // 2 + 1), dtype=torch.complex64, device=self.device)
+        else:
+            self._check_out(out, (R, n // 2 + 1), torch.complex64, "rfft")
         _lib.check(self._lib.mm_rfft_f32(self._h, rows.data_ptr(), R, L, rows.stride(0), int(n),
                                          out.data_ptr(), self._stream()), "mm_rfft_f32")
         return out
@@ -285,9 +309,13 @@ class MfccPlan:
         mfcc = mfcc.contiguous()
         B, _, T = mfcc.shape
         n = self.cfg.mod_fft_len(T)
+        if mfcc.device != self.device:
+            raise ValueError(f"mfcc is on {mfcc.device}, the plan on {self.device}")
         if out is None:
             out = torch.empty((B, self.cfg.n_mfcc, n // 2 + 1), dtype=torch.complex64,
                               device=self.device)
+        else:
+            self._check_out(out, (B, self.cfg.n_mfcc, n // 2 + 1), torch.complex64, "modspec")
         _lib.check(self._lib.mm_modspec_f32(self._h, mfcc.data_ptr(), B, T, out.data_ptr(),
                                             self._stream()), "mm_modspec_f32")
         return out

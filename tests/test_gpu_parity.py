@@ -869,6 +869,30 @@ def test_load_and_resample_on_device(tmp_path, gpu):
     assert c.shape == (201,) and np.isfinite(c).all()
 
 
+def test_caller_provided_outputs_are_validated(gpu):
+    """plan.mfcc / modspec / rfft hand out.data_ptr() to the C ABI: a wrong shape, dtype, stride or device is
+    refused on the host instead of becoming an out-of-bounds device write."""
+    import torch
+    kw, y, _ = load_golden("c1_am")
+    plan = _plan(kw)
+    d = _dev(y, gpu)[None, :]
+    T = plan.cfg.num_frames(y.shape[0])
+    good = torch.empty((1, 13, T), dtype=torch.float32, device=gpu)
+    assert plan.mfcc(d, out=good) is good
+    for bad in (torch.empty((1, 13, T - 1), device=gpu), torch.empty((1, 13, T), dtype=torch.float64, device=gpu),
+                torch.empty((1, 13, 2 * T), device=gpu)[:, :, ::2], torch.empty((1, 13, T))):
+        with pytest.raises((ValueError, TypeError)):
+            plan.mfcc(d, out=bad)
+    with pytest.raises(ValueError):
+        plan.modspec(good, out=torch.empty((1, 13, 10), dtype=torch.complex64, device=gpu))
+    with pytest.raises(ValueError):
+        plan.rfft(torch.zeros((4, 512), device=gpu), 512, out=torch.empty((4, 256), dtype=torch.complex64, device=gpu))
+    # clips beyond 2^29 - 8192 samples are refused before anything is launched (32-bit sample offsets in the kernels)
+    ws = plan.workspace(1, y.shape[0])
+    rc = plan._lib.mm_mfcc_f32(plan._h, d.data_ptr(), 1, (1 << 29) - 8191, 1 << 30, good.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == -1
+
+
 def test_plans_with_different_lds_sizes_coexist(gpu):
     """The dynamic-LDS limit is a per-function attribute: creating a plan with a small mel table after
     one with a large table must not break launches of the first (n_mels 128 needs more LDS than 40)."""
