@@ -6,10 +6,15 @@ and ``spectrogram(center=True, pad_mode='constant', power=2, log_mel='dB',
 db_range=80)``.  It is NOT the reference and does not pin parity; it guards the
 restatement in ``mfcc_oracle.py`` against transcription mistakes.  Run:
 
-    python oracle/crosscheck_transformers.py
+    python oracle/crosscheck_transformers.py [--write]
 
 Prints one line per case and exits non-zero when any case disagrees by more
-than 1e-5 of max|MFCC| (float32 round-off is ~2e-7).
+than 1e-5 of max|MFCC| (float32 round-off is ~2e-7).  ``--write`` stores the
+independent implementation's MFCCs (not the oracle's) as tests/golden_xcheck/*.npz
+-- input RECIPE + configuration + expected array -- so that the oracle (CPU suite) and
+the HIP path (GPU suite) are also asserted against numbers this repository did not
+produce, on machines where transformers is absent.  They are evidence, not a pin:
+the reference itself ships no vectors.
 """
 import os
 import sys
@@ -47,6 +52,8 @@ def transformers_mfcc(y, sr, n_fft, win, hop, n_mels, n_mfcc, fmin, fmax):
 
 def main():
     worst = 0.0
+    write = "--write" in sys.argv
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden_xcheck")
     for (name, sr, n_fft, win, hop, n_mels, n_mfcc, fmin, fmax, secs, kind) in CASES:
         n = int(sr * secs)
         y = O.synth_clip(7, n, sr, kind)
@@ -60,6 +67,13 @@ def main():
         d = float(np.max(np.abs(ours - theirs)))
         rel = d / float(np.max(np.abs(theirs)))
         worst = max(worst, rel)
+        if write and theirs.nbytes <= 40000:
+            import transformers
+            os.makedirs(outdir, exist_ok=True)
+            keys = ["sr", "n_fft", "win_length", "hop_length", "n_mels", "n_mfcc", "fmin", "fmax"]
+            np.savez_compressed(os.path.join(outdir, name + ".npz"), recipe=np.array([7, n], dtype=np.int64), kind=np.array(kind),
+                                cfg_keys=np.array(keys), cfg_vals=np.array([sr, n_fft, win, hop, n_mels, n_mfcc, fmin, fmax], dtype=np.float64),
+                                mfcc=theirs, source=np.array(f"transformers {transformers.__version__} audio_utils + scipy.fftpack.dct"))
         print(f"{name:14s} frames={ours.shape[1]:5d} mel max|dW|={dW:.2e} "
               f"mfcc max|d|={d:.3e} rel-to-max={rel:.2e} empty_filters={(Wo.max(1) == 0).sum()}")
     print("worst rel:", worst)

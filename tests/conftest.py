@@ -29,6 +29,22 @@ def load_golden(name):
     return kw, y, {k: z[k] for k in z.files}
 
 
+XCHECK = os.path.join(ROOT, "tests", "golden_xcheck")
+XCHECK_NAMES = sorted(f[:-4] for f in os.listdir(XCHECK) if f.endswith(".npz")) if os.path.isdir(XCHECK) else []
+
+
+def load_xcheck(name):
+    """Fixture written by oracle/crosscheck_transformers.py --write: MFCCs of an INDEPENDENT librosa-compatible
+    implementation (transformers.audio_utils + scipy.fftpack.dct) -> (cfg kwargs, regenerated input, expected)."""
+    import mfcc_oracle as O
+    z = np.load(os.path.join(XCHECK, name + ".npz"))
+    kw = {k: v for k, v in zip(z["cfg_keys"].tolist(), z["cfg_vals"].tolist())}
+    for k in ("sr", "n_fft", "win_length", "hop_length", "n_mels", "n_mfcc"):
+        kw[k] = int(kw[k])
+    seed, n = (int(v) for v in z["recipe"])
+    return kw, O.synth_clip(seed, n, kw["sr"], str(z["kind"])), z["mfcc"]
+
+
 GOLDEN_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz")) \
     if os.path.isdir(GOLDEN) else []
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import mfcc_oracle as O
-from conftest import GOLDEN_NAMES, load_golden, mfcc_close
+from conftest import GOLDEN_NAMES, XCHECK_NAMES, load_golden, load_xcheck, mfcc_close
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +60,15 @@ def test_mfcc_matches_golden(name, variant, gpu):
     with _variant(plan, variant):
         got = plan.mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
     mfcc_close(got, exp["mfcc"], f"{name} {variant}")
+
+
+@pytest.mark.parametrize("name", XCHECK_NAMES)
+def test_mfcc_matches_the_independent_implementation(name, gpu):
+    """The HIP path against MFCCs of transformers.audio_utils + scipy.fftpack.dct (tests/golden_xcheck, written
+    by oracle/crosscheck_transformers.py --write): numbers neither the oracle nor the kernels produced."""
+    kw, y, want = load_xcheck(name)
+    got = _plan(kw).mfcc(_dev(y, gpu)[None, :])[0].cpu().numpy()
+    mfcc_close(got, want, f"xcheck {name}")
 
 
 @pytest.mark.parametrize("n", [4, 8, 160, 252, 256, 260, 512, 10236, 10240, 10244, 16000, 40964])

@@ -87,3 +87,16 @@ def test_rms_envelope():
     x = np.ones(1000, dtype=np.float32)
     r = O.rms_envelope(x, 100, 10)
     assert r.shape == (101,) and r[50] == pytest.approx(1.0) and r[0] == pytest.approx(np.sqrt(0.5))
+
+
+def test_oracle_matches_the_independent_implementation():
+    """tests/golden_xcheck/*.npz hold MFCCs computed by transformers.audio_utils (documented librosa
+    compatibility) + scipy.fftpack.dct -- numbers this repository did not produce.  The oracle agrees to
+    float32 round-off.  Evidence, not a pin (the reference ships no vectors)."""
+    from conftest import XCHECK_NAMES, load_xcheck
+    assert len(XCHECK_NAMES) >= 5
+    for name in XCHECK_NAMES:
+        kw, y, want = load_xcheck(name)
+        got = O.mfcc(y, O.OracleConfig(**kw))
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), name
