@@ -37,16 +37,27 @@ def main():
         if rng.random() < 0.7: n = max(4, n // 4 * 4)
         B = int(rng.integers(1, 6))
         clips = np.stack([O.synth_clip(1000 * seed + 10 * idx + i, n, sr, ("am", "noise", "quiet_tail")[i % 3]) for i in range(B)])
-        got = plan.mfcc(torch.from_numpy(clips).cuda()).cpu().numpy()
-        paths[plan.kernel_path] = paths.get(plan.kernel_path, 0) + 1
+        d = torch.from_numpy(clips).cuda()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
+            wants = [O.mfcc(clips[i], O.OracleConfig(**okw)) for i in range(B)]
+        # default kernel (DCT fused where the plan can), the same without the fused DCT, and the matrix-pipe variant
+        for mode in ("default", "nofuse", "m12"):
+            plan.set_variant("m12" if mode == "m12" else None)
+            plan.set_fuse_dct(mode != "nofuse")
+            if mode == "m12" and plan.kernel_path != "radix16-m12":
+                continue
+            if mode == "nofuse" and not plan.fused_dct and idx % 4:
+                pass
+            got = plan.mfcc(d).cpu().numpy()
+            key = plan.kernel_path + ("+dct" if plan.fused_dct else "")
+            paths[key] = paths.get(key, 0) + 1
             for i in range(B):
-                want = O.mfcc(clips[i], O.OracleConfig(**okw))
+                want = wants[i]
                 ok, rel = close(got[i], want) if got[i].shape == want.shape else (False, -1)
                 if not ok:
                     bad += 1
-                    print("MISMATCH", idx, plan.kernel_path, kw, "n", n, "clip", i, "rel", rel, flush=True)
+                    print("MISMATCH", idx, mode, key, kw, "n", n, "clip", i, "rel", rel, flush=True)
         if idx % 25 == 0: print("..", idx, paths, flush=True)
     print("done", n_cfg, "configs, mismatches:", bad, paths)
     sys.exit(1 if bad else 0)
