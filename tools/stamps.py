@@ -13,7 +13,7 @@ torch.cuda.synchronize()
 lib = _lib.load()
 out = (ctypes.c_uint * 256)()
 assert lib.mm_debug_stamps(out) == 0
-a = np.array(out[:]).reshape(16, 16)[:, :12]
+a = np.array(out[:]).reshape(16, 16)[:, :16]
 tiles = 16016 // 256
 np.set_printoptions(linewidth=200)
 print("cycles per tile, per wave (rows) x section (cols):")
