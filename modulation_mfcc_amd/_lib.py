@@ -120,6 +120,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: its wheel bundles the HIP runtime (torch/lib/libamdhip64.so), libmodmfcc.so was linked against
+    # /opt/rocm's.  Whichever is loaded first serves both (same SONAME); loaded the other way round the process
+    # ends up with two runtimes and the second one finds no device ("hipGetDevice failed").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
