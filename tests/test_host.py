@@ -176,3 +176,44 @@ def test_resampler_quality(sr_in, sr_out):
     if sr_out < sr_in:
         alias = scipy.signal.resample_poly(np.sin(2 * np.pi * 1.2 * f_lo * t_in), L, M, window=h / L)
         assert 20 * np.log10(np.abs(alias[mid]).max()) < -115.0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(method="gradient", difference=1), dict(method="gradient", difference=2),
+    dict(method="sg", width=3, polyOrder=2, difference=1), dict(method="sg", width=7, polyOrder=3, difference=2),
+    dict(method="sg", width=11, polyOrder=2, difference=1), dict(method="sg", width=9, polyOrder=3, difference=0),
+    dict(method="finDiff", difference=1, accOrder=2), dict(method="finDiff", difference=2, accOrder=4),
+    dict(method="finDiff", difference=1, accOrder=6),
+])
+def test_velocity_stencils_on_the_host(kw):
+    """Row N2, host part: the banded operator calc.velocity_stencil hands to mm_stencil_f64 -- interior taps, dense
+    rows for the first / last samples, denominators -- applied with numpy reproduces get_velocity's host
+    arithmetic (np.gradient exactly; scipy's savgol_filter(mode='interp') and the findiff stencils to round-off).
+    The kernel applies exactly this arithmetic (tests/test_gpu_parity.py::test_velocity_on_device)."""
+    from modulation_mfcc_amd.calc import velocity_stencil
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(200).cumsum()
+    st, passes = velocity_stencil(200.0, **kw)
+    assert len(st["c"]) <= 16 and st["n_edge"] <= 8 and st["edge_w"] <= 16
+    y = x
+    for _ in range(passes):
+        n = len(y)
+        out = np.empty(n)
+        for i in range(n):
+            if i < st["n_edge"]:
+                out[i] = np.dot(st["el"][i], y[:st["edge_w"]]) / st["den_e"]
+            elif i >= n - st["n_edge"]:
+                out[i] = np.dot(st["er"][i - (n - st["n_edge"])], y[n - st["edge_w"]:]) / st["den_e"]
+            else:
+                out[i] = sum(c * y[i + o] for c, o in zip(st["c"], st["off"])) / st["den_c"]
+        y = out
+    if kw["method"] == "sg" and kw["difference"] == 0:
+        want = scipy.signal.savgol_filter(x, kw["width"], kw["polyOrder"], deriv=0, mode="interp")
+    else:
+        want = get_velocity(x, 200.0, **kw)
+    if kw["method"] == "gradient":
+        np.testing.assert_array_equal(y, want)
+    else:
+        assert np.abs(y - want).max() <= 1e-13 * np.abs(want).max()
+    with pytest.raises(NotImplementedError):
+        velocity_stencil(200.0, 1, "sg", 21, 2, 3)
