@@ -325,6 +325,9 @@ struct mm_plan {
   unsigned m12_win_off, m12_tw_off, m12_a_off, m12_dct_off, m12_part_off, m12_cnt_off;
   int m12_n_a2;
   size_t m12_lds_bytes;
+  float* d_dctfm_a;                // dct_clamp_fm_mfma_kernel: A operands [kb][nk][64] (nullptr: VALU kernel)
+  int dctfm_nk, dctfm_kb;
+  size_t dctfm_lds;
   int variant;                     // mm_plan_set_variant: 0 = automatic
   int no_fuse;                     // mm_plan_set_fuse_dct(0): always run the separate clamp + DCT kernel
 
@@ -587,7 +590,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0;
-  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0;
+  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->d_dctfm_a = nullptr;
   p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
@@ -871,6 +874,20 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
           upload(&p->d_k2_mel_lane, ml.data(), ml.size() * 4) == MM_OK &&
           set_dct_fm_attr(64 * (MM_WPF_MAXMEL + 1) * 4))
         p->k2_ok = 1;
+      if (p->k2_ok) {      // A operands of the matrix-pipe clamp + DCT kernel: dct[16 kb + (l & 15)][4 s + (l >> 4)]
+        const int nk = (cfg->n_mels + 3) / 4, kbn = (cfg->n_mfcc + 15) / 16;
+        const size_t lds = ((size_t)64 * ((4 * nk) | 1) + (size_t)kbn * nk * 64) * 4;
+        if (lds <= 65536 && cfg->n_mels <= 128) {      // the kernel's loader holds 64 frames x 128 filters in registers
+          std::vector<float> da((size_t)kbn * nk * 64, 0.0f);
+          for (int kb = 0; kb < kbn; ++kb)
+            for (int s2 = 0; s2 < nk; ++s2)
+              for (int l = 0; l < 64; ++l) {
+                const int k = 16 * kb + (l & 15), m = 4 * s2 + (l >> 4);
+                if (k < cfg->n_mfcc && m < cfg->n_mels) da[((size_t)kb * nk + s2) * 64 + l] = dct[(size_t)k * cfg->n_mels + m];
+              }
+          if (upload(&p->d_dctfm_a, da.data(), da.size() * 4) == MM_OK) { p->dctfm_nk = nk; p->dctfm_kb = kbn; p->dctfm_lds = lds; }
+        }
+      }
     }
   }
   if (hipFuncSetAttribute((const void*)rfft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) !=
@@ -909,6 +926,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane); (void)hipFree(p->d_window_e);
   (void)hipFree(p->d_rf2k_lane_tab);
   (void)hipFree(p->d_m12_a); (void)hipFree(p->d_m12_dct); (void)hipFree(p->d_zeros);
+  (void)hipFree(p->d_dctfm_a);
   (void)hipFree(p->d_s16f_tab); (void)hipFree(p->d_s16f_dcta); (void)hipFree(p->d_s16f_part);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
@@ -1200,6 +1218,14 @@ int mm_mfcc_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_sampl
       if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
       hipLaunchKernelGGL(dct_fixup_kernel, dim3((unsigned)(batch * bpc)), dim3(256), 0, st, logmel, keys, keys + batch,
                          p->d_dct_t, d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
+    } else if (o.is_fm && p->d_dctfm_a && !p->no_fuse) {
+      // frame-major rows of the wave-per-frame kernel: clamp + DCT on the matrix pipe
+      const int64_t bpc = (T + 63) / 64;
+      if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+      const int64_t n_tiles = batch * bpc, per_cu = std::max<int64_t>(1, std::min<int64_t>(8, 163840 / (int64_t)p->dctfm_lds));
+      const int64_t grid = std::min<int64_t>(n_tiles, per_cu * p->num_cus);      // persistent: A operands loaded once
+      hipLaunchKernelGGL(dct_clamp_fm_mfma_kernel, dim3((unsigned)grid), dim3(256), p->dctfm_lds, st, logmel, keys,
+                         p->d_dctfm_a, d_mfcc, T, n_tiles, p->cfg.n_mels, p->cfg.n_mfcc, p->dctfm_nk, p->dctfm_kb, p->cfg.top_db);
     } else if (o.is_fm) {
       const int64_t bpc = (T + 63) / 64;
       if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
