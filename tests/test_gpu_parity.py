@@ -902,6 +902,42 @@ def test_caller_provided_outputs_are_validated(gpu):
     assert rc == -1
 
 
+def test_edge_sizes_of_the_side_kernels(gpu):
+    """Smallest and oddest inputs of the round-2 entry points: resampling clips of 1 .. 3 samples and by 3 / 1,
+    an empty WAVE data chunk, stencils on the shortest admissible curve, one-row batches, non-contiguous input."""
+    import scipy.signal
+    import torch
+    from modulation_mfcc_amd import resample_batch, velocity_batch, sosfiltfilt_batch, rms_batch
+    from modulation_mfcc_amd.audio_io import design_taps, resample_ratio
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 3, 17):
+        for sr_in, sr_out in ((48000, 16000), (16000, 48000), (44100, 16000)):
+            x = rng.standard_normal((2, n)).astype(np.float32)
+            got = resample_batch(_dev(x, gpu), sr_in, sr_out).cpu().numpy()
+            L, M = resample_ratio(sr_in, sr_out)
+            h, _ = design_taps(L, M)
+            want = scipy.signal.resample_poly(x.astype(np.float64), L, M, axis=1, window=h.astype(np.float32).astype(np.float64) / L)
+            assert got.shape == want.shape == (2, -(-n * L // M))
+            np.testing.assert_allclose(got, want, rtol=0, atol=3e-6 * max(1.0, np.abs(want).max()))
+    one = resample_batch(_dev(x[0], gpu), 16000, 8000)
+    assert one.shape == (9,)
+    # strided rows
+    big = torch.zeros((3, 50), dtype=torch.float64, device=gpu)
+    big[:, ::2] = _dev(rng.standard_normal((3, 25)), gpu)
+    v = velocity_batch(big[:, ::2], 100.0)
+    np.testing.assert_array_equal(v.cpu().numpy(), np.gradient(big[:, ::2].cpu().numpy(), 0.01, axis=1))
+    two = velocity_batch(_dev(np.array([[1.0, 4.0]]), gpu), 10.0)               # n = 2: both outputs are edge rows
+    np.testing.assert_array_equal(two.cpu().numpy(), np.gradient(np.array([[1.0, 4.0]]), 0.1, axis=1))
+    with pytest.raises(ValueError):
+        velocity_batch(_dev(np.array([[1.0]]), gpu), 10.0)
+    sos = scipy.signal.butter(2, 0.3, output="sos")
+    xr = rng.standard_normal((1, 10))
+    np.testing.assert_allclose(sosfiltfilt_batch(_dev(xr, gpu), sos).cpu().numpy(), scipy.signal.sosfiltfilt(sos, xr, axis=1),
+                               rtol=1e-9, atol=1e-12)
+    r = rms_batch(_dev(np.ones((1, 5), dtype=np.float32), gpu), 4, 2, True)
+    np.testing.assert_allclose(r.cpu().numpy(), O.rms_envelope(np.ones(5, dtype=np.float32), 4, 2, True)[None, :], rtol=1e-6)
+
+
 def test_plans_with_different_lds_sizes_coexist(gpu):
     """The dynamic-LDS limit is a per-function attribute: creating a plan with a small mel table after
     one with a large table must not break launches of the first (n_mels 128 needs more LDS than 40)."""
