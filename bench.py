@@ -180,10 +180,20 @@ def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=No
     bytes_launch = alg[dom] * B * T
     ach = bytes_launch / (per_stage[dom]["avg_ms"] * 1e-3) / 1e9
     traffic, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
-    return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
-            "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_frame": alg[dom],
-            "avg_launch_ms": per_stage[dom]["avg_ms"]}
+    out = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+           "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_frame": alg[dom],
+           "avg_launch_ms": per_stage[dom]["avg_ms"]}
+    if dom == "logmel":
+        # for information: the fused kernel is issue / LDS bound, not HBM bound -- its
+        # algorithmic flops (rFFT 2.5 N log2 N + power + sparse mel + log + DCT) against the FP32 vector peak
+        n = cfg.n_fft
+        import math
+        flops = 2.5 * n * math.log2(n) + 3 * (n // 2 + 1) + 4 * (n // 2 + 1) + cfg.n_mels + (2 * cfg.n_mels * cfg.n_mfcc if fused_dct else 0)
+        tf = flops * B * T / (per_stage[dom]["avg_ms"] * 1e-3) / 1e12
+        out["fp32_vector"] = {"algorithmic_flops_per_frame": flops, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                              "frac": tf / 157.3}
+    return out
 
 
 def main():
