@@ -12,7 +12,7 @@ from scipy.signal import savgol_filter
 
 from .filters import applyFilter
 
-__all__ = ["applyFilter", "get_velocity", "calculate_amplitude_envelope", "velocity_stencil", "velocity_batch",
+__all__ = ["applyFilter", "get_velocity", "calculate_amplitude_envelope", "velocity_stencil", "velocity_batch", "apply_stencil",
            "hilbert_envelope_batch", "amplitude_envelope_batch"]
 
 
@@ -202,14 +202,40 @@ def velocity_stencil(sr: float, difference: int = 1, method: str = "gradient", w
     raise ValueError("Méthode inconnue. Utilisez 'gradient', 'sg' ou 'finDiff'.")
 
 
+def apply_stencil(x2, st, passes: int = 1):
+    """Run the banded operator ``st`` (dict: off, c, den_c, n_edge, edge_w, el, er, den_e -- the fields of the C
+    struct mm_stencil) ``passes`` times along the last axis of a float64 CUDA(HIP) tensor [rows, n] with unit
+    inner stride (mm_stencil_f64)."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    rows, n = x2.shape
+    cs = _lib.mm_stencil()
+    cs.n_c, cs.n_edge, cs.edge_w = len(st["c"]), st["n_edge"], st["edge_w"]
+    for k, (o, c) in enumerate(zip(st["off"], st["c"])):
+        cs.off[k], cs.c[k] = o, c
+    for i in range(st["n_edge"]):
+        for j in range(st["edge_w"]):
+            cs.el[i][j], cs.er[i][j] = st["el"][i][j], st["er"][i][j]
+    cs.den_c, cs.den_e = st["den_c"], st["den_e"]
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
+    with torch.cuda.device(x2.device):
+        src = x2
+        for _ in range(passes):
+            out = torch.empty((rows, n), dtype=torch.float64, device=x2.device)
+            _lib.check(lib.mm_stencil_f64(C.byref(cs), src.data_ptr(), rows, n, src.stride(0), out.data_ptr(), stream),
+                       "mm_stencil_f64")
+            src = out
+    return src
+
+
 def velocity_batch(x, sr: float, difference: int = 1, method: str = "gradient", width: int = 3,
                    accOrder: int = 2, polyOrder: int = 2):
     """get_velocity along the LAST axis of a float64 CUDA(HIP) tensor [rows, n] (or [n]) on the device
     (mm_stencil_f64; row N2) -- e.g. on the [B, T] output of MfccPlan.mfcc_change.  'gradient' equals
     np.gradient(x, 1/sr) bit for bit, 'sg' / 'finDiff' agree with scipy / findiff to float64 round-off."""
-    import ctypes as C
     import torch
-    from . import _lib
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64):
         raise TypeError("x must be a float64 CUDA(HIP) tensor")
     st, passes = velocity_stencil(sr, difference, method, width, accOrder, polyOrder)
@@ -224,23 +250,7 @@ def velocity_batch(x, sr: float, difference: int = 1, method: str = "gradient", 
         raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
     if n < max(2 * st["n_edge"], st["edge_w"]):
         raise ValueError("signal too short for the requested finite-difference stencil")
-    cs = _lib.mm_stencil()
-    cs.n_c, cs.n_edge, cs.edge_w = len(st["c"]), st["n_edge"], st["edge_w"]
-    for k, (o, c) in enumerate(zip(st["off"], st["c"])):
-        cs.off[k], cs.c[k] = o, c
-    for i in range(st["n_edge"]):
-        for j in range(st["edge_w"]):
-            cs.el[i][j], cs.er[i][j] = st["el"][i][j], st["er"][i][j]
-    cs.den_c, cs.den_e = st["den_c"], st["den_e"]
-    lib = _lib.load()
-    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-    with torch.cuda.device(x.device):
-        src = x2
-        for _ in range(passes):
-            out = torch.empty((rows, n), dtype=torch.float64, device=x.device)
-            _lib.check(lib.mm_stencil_f64(C.byref(cs), src.data_ptr(), rows, n, src.stride(0), out.data_ptr(), stream),
-                       "mm_stencil_f64")
-            src = out
+    src = apply_stencil(x2, st, passes)
     return src[0] if squeeze else src
 
 

@@ -1,7 +1,7 @@
 """``applyFilter`` -- shared by the reference's script/mfcc.py:29-135 and script/calc.py:23-129
-(the two copies are identical in behaviour).  Filter DESIGN and the fir / sg variants are scipy
-calls on the host exactly as in the reference; this is post-processing of short curves
-(one value per frame), not the hot path.
+(the two copies are identical in behaviour).  Filter DESIGN (butter, firwin, savgol_coeffs) is scipy on the
+host exactly as in the reference.  numpy input is filtered by the reference's own scipy calls; float64 curves
+that live on the GPU are filtered there (mm_sosfiltfilt_f64, mm_stencil_f64) -- SURVEY.md 8(f) row N1.
 """
 from __future__ import annotations
 
@@ -89,10 +89,55 @@ def sosfiltfilt_batch(x, sos):
     return out[0] if squeeze else out
 
 
+def fir_filtfilt_stencil(taps):
+    """scipy.signal.filtfilt(taps, 1, x) -- the 'fir' branch of applyFilter (script/mfcc.py:113-126) -- as the
+    banded operator mm_stencil_f64 applies.  filtfilt pads x by an odd extension of 3 * len(taps) samples, runs
+    the filter forwards and backwards from lfilter_zi states and crops the padding; for an FIR filter the two
+    start-up transients (len(taps) - 1 samples each) lie inside the cropped padding, so every kept output is
+    the correlation of the extended signal with h = taps (*) reversed taps.  Inside that is the symmetric stencil
+    h; the first / last len(taps) - 1 outputs fold the taps that reach the extension x_ext[-m] = 2 x[0] - x[m]
+    back onto the signal.  Raises NotImplementedError when it does not fit the C struct (more than 8 taps; or a single tap,
+    which scipy rejects)."""
+    from . import _lib
+    b = np.asarray(taps, dtype=np.float64).ravel()
+    L = len(b)
+    if L < 2 or 2 * L - 1 > _lib.MM_ST_MAXW or L - 1 > _lib.MM_ST_MAXE:     # one tap: scipy's lfilter_zi raises
+        raise NotImplementedError("FIR filter too long (or too short) for the device stencil")
+    h = np.convolve(b, b[::-1])                      # h[d + L - 1], d = -(L-1) .. L-1 (symmetric)
+    half = L - 1
+    ew = 2 * half
+    el = np.zeros((half, ew))
+    for i in range(half):
+        for d in range(-half, half + 1):
+            j = i + d
+            if j >= 0:
+                el[i, j] += h[d + half]
+            else:                                    # odd extension about x[0]
+                el[i, 0] += 2.0 * h[d + half]
+                el[i, -j] -= h[d + half]
+    er = el[::-1, ::-1]                              # the same fold about x[n - 1]
+    return dict(off=list(range(-half, half + 1)), c=[float(v) for v in h], den_c=1.0, n_edge=half, edge_w=ew,
+                el=el.tolist(), er=np.ascontiguousarray(er).tolist(), den_e=1.0)
+
+
+def _stencil_rows(x, st):
+    import torch
+    from .calc import apply_stencil
+    squeeze = x.dim() == 1
+    x2 = x.unsqueeze(0) if squeeze else x
+    if x2.dim() != 2:
+        raise ValueError("x must be [n] or [rows, n]")
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    y = apply_stencil(x2, st, 1)
+    return y[0] if squeeze else y
+
+
 def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs):
     """applyFilter for float64 CUDA(HIP) curves ([n] or [rows, n], along the last axis): 'iir' through
-    mm_sosfiltfilt_f64, 'sg' through the banded-operator kernel (mm_stencil_f64); 'fir' has no device kernel
-    and makes the round trip through the host (scipy.signal.filtfilt, as in the reference)."""
+    mm_sosfiltfilt_f64, 'sg' and 'fir' through the banded-operator kernel (mm_stencil_f64).  Windows / tap
+    counts beyond the C struct (Savitzky-Golay windows over 16 samples, FIR filters over 8 taps) make the round
+    trip through the host (the reference's own scipy calls)."""
     import torch
     if x.dtype != torch.float64:
         x = x.double()                      # scipy filters in float64 whatever the input type
@@ -108,6 +153,17 @@ def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs)
             return velocity_batch(x, 1.0, 0, "sg", filtLen, 2, polyOrd)
         except NotImplementedError:
             pass
+    if filt == "fir":
+        taps = np.asarray(coeffs) if coeffs is not None else \
+            _sig.firwin(filtLen, _band_edges(cutOff, sr, kind), window=("kaiser", 7.4), pass_zero=kind)
+        try:
+            st = fir_filtfilt_stencil(taps)
+        except NotImplementedError:
+            st = None
+        if st is not None:
+            if x.shape[-1] <= 3 * len(taps):   # scipy.signal.filtfilt's own check and message
+                raise ValueError(f"The length of the input vector x must be greater than padlen, which is {3 * len(taps)}.")
+            return _stencil_rows(x, st)
     if filt in ("fir", "sg"):
         y = applyFilter(x.cpu().numpy(), sr, filt=filt, cutOff=cutOff, filtLen=filtLen,
                         filtType=kind[:-4], polyOrd=polyOrd, coeffs=coeffs)

@@ -99,7 +99,7 @@ def get_MFCCS_change(audioIn, sigSr, /, *, channelN: int = 0, tStep: float = 0.0
                                           filtCutoff=filtCutoff, filtOrd=filtOrd, diffMethod=diffMethod,
                                           outFilter=outFilter,
                                           outFiltType=outFiltType, outFiltCutOff=outFiltCutOff,
-                                          outFiltLen=outFiltLen)[0].cpu().numpy()
+                                          outFiltLen=outFiltLen, outFiltPolyOrd=outFiltPolyOrd)[0].cpu().numpy()
         return change, anchors
     coeffs = mfcc_array(signal.cpu().numpy() if hasattr(signal, "is_cuda") else signal, cfg)
     anchors = _tail.time_anchors(coeffs.shape[1], tStep, winLen)

@@ -320,10 +320,11 @@ class MfccPlan:
                                             self._stream()), "mm_modspec_f32")
         return out
 
-    def mfcc_change(self, mfcc, sos1, sos2=None, remove_first=True, diff_method="grad"):
+    def mfcc_change(self, mfcc, sos1, sos2=None, remove_first=True, diff_method="grad", out_filter=True):
         """MFCC-change tail on the device (script/mfcc.py:392-427): [B, n_mfcc, T] float32 -> [B, T]
         float64.  sos1 / sos2: SOS arrays [n_sec, 6] (host); sos2 None applies sos1 again (the reference's
-        outFilter=None branch).  diff_method 'grad' = np.gradient, anything else = the reference's
+        outFilter=None branch); out_filter=False stops after the norm (the caller applies a 'fir' / 'sg'
+        output filter to the result).  diff_method 'grad' = np.gradient, anything else = the reference's
         Savitzky-Golay differentiator savgol_filter(x, 3, 2, deriv=1, mode='interp')."""
         torch = _torch()
         if not (isinstance(mfcc, torch.Tensor) and mfcc.is_cuda and mfcc.dtype == torch.float32
@@ -333,7 +334,7 @@ class MfccPlan:
         B, _, T = mfcc.shape
         s1 = np.ascontiguousarray(np.asarray(sos1, dtype=np.float64).reshape(-1, 6))
         s2 = s1 if sos2 is None else np.ascontiguousarray(np.asarray(sos2, dtype=np.float64).reshape(-1, 6))
-        for s in (s1, s2):
+        for s in ((s1, s2) if out_filter else (s1,)):
             ntaps = 2 * s.shape[0] + 1 - min(int((s[:, 2] == 0).sum()), int((s[:, 5] == 0).sum()))
             if T <= 3 * ntaps:   # scipy.signal.sosfiltfilt's own check and message
                 raise ValueError("The length of the input vector x must be greater than padlen, "
@@ -345,7 +346,7 @@ class MfccPlan:
         need = int(self._lib.mm_change_workspace_bytes(self._h, B, T))
         ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         _lib.check(self._lib.mm_mfcc_change_f64(self._h, mfcc.data_ptr(), B, T, 1 if remove_first else 0, sg,
-                                                s1.ctypes.data, s1.shape[0], s2.ctypes.data, s2.shape[0],
+                                                s1.ctypes.data, s1.shape[0], s2.ctypes.data, s2.shape[0] if out_filter else 0,
                                                 out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                    "mm_mfcc_change_f64")
         return out

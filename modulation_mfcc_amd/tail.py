@@ -6,9 +6,9 @@ after the librosa call.  SURVEY.md 8(f) row N1.
 
 The filter DESIGN is host arithmetic in the reference (scipy.signal.butter) and stays so.  The
 filtering runs on the device (``mm_mfcc_change_f64``, float64 like scipy) for both differentiators
-(np.gradient, and the Savitzky-Golay derivative every other ``diffMethod`` selects) with an IIR output
-filter or none, and through the reference's own scipy calls (on the MFCC matrix the device returned) for
-the fir / sg OUTPUT filters.
+(np.gradient, and the Savitzky-Golay derivative every other ``diffMethod`` selects) and every output filter:
+IIR or none inside ``mm_mfcc_change_f64``, 'fir' / 'sg' as a banded operator on its result (``mm_stencil_f64``;
+tap counts beyond that struct go through the host, filters._apply_filter_device).
 """
 from __future__ import annotations
 
@@ -30,14 +30,20 @@ def design_lowpass(filtOrd: int, filtCutoff: float, tStep: float) -> np.ndarray:
 
 
 def device_path_applies(diffMethod, outFilter) -> bool:
-    return outFilter is None or outFilter == "iir"
+    return outFilter is None or outFilter in ("iir", "fir", "sg")
 
 
 def mfcc_change_device(plan, mfcc_dev, *, tStep: float, removeFirst=1, filtCutoff=12, filtOrd=6,
-                       diffMethod="grad", outFilter="iir", outFiltType="low", outFiltCutOff=(None,), outFiltLen=6):
+                       diffMethod="grad", outFilter="iir", outFiltType="low", outFiltCutOff=(None,), outFiltLen=6,
+                       outFiltPolyOrd=3):
     """Device version of ``mfcc_change`` for [B, n_mfcc, T] MFCCs already on the GPU -> [B, T] f64
     tensor.  Raises exactly what the host version raises for bad filter arguments."""
     sos1 = design_lowpass(filtOrd, filtCutoff, tStep)
+    if outFilter in ("fir", "sg"):
+        change = plan.mfcc_change(mfcc_dev, sos1, None, remove_first=bool(removeFirst), diff_method=diffMethod,
+                                  out_filter=False)
+        return applyFilter(change, 1 / tStep, filt=outFilter, filtType=outFiltType, cutOff=outFiltCutOff,
+                           filtLen=outFiltLen, polyOrd=outFiltPolyOrd)
     sos2 = None if outFilter is None else iir_sos(1 / tStep, cutOff=outFiltCutOff, filtLen=outFiltLen,
                                                   filtType=outFiltType)
     return plan.mfcc_change(mfcc_dev, sos1, sos2, remove_first=bool(removeFirst), diff_method=diffMethod)

@@ -627,10 +627,16 @@ def test_ragged_lengths_fast_and_generic(n, gpu):
     dict(filtOrd=5, filtCutoff=8, outFiltCutOff=[10], outFiltLen=3),
     dict(outFiltType="band", outFiltCutOff=[2, 20]), dict(outFiltType="high", outFiltCutOff=[3]),
     dict(diffMethod="sg", outFiltCutOff=[12]), dict(diffMethod="sg", outFilter=None, removeFirst=0),
+    dict(outFilter="fir", outFiltCutOff=[12]), dict(outFilter="fir", outFiltType="high", outFiltCutOff=[5], outFiltLen=7),
+    dict(outFilter="fir", outFiltType="band", outFiltCutOff=[2, 20], outFiltLen=8, diffMethod="sg"),
+    dict(outFilter="sg", outFiltCutOff=[12], outFiltLen=7, outFiltPolyOrd=3),
+    dict(outFilter="sg", outFiltCutOff=[12], outFiltLen=15, outFiltPolyOrd=2, removeFirst=0),
+    dict(outFilter="fir", outFiltCutOff=[12], outFiltLen=21),       # beyond the device stencil: host round trip
 ])
 def test_change_tail_on_device(kwargs, gpu):
     """Row N1: mm_mfcc_change_f64 against scipy's sosfiltfilt / gradient / savgol_filter (the reference's
-    tail, script/mfcc.py:392-427, both differentiators)."""
+    tail, script/mfcc.py:392-427, both differentiators; the 'fir' / 'sg' output filters as a banded operator
+    on the device)."""
     from modulation_mfcc_amd import tail
     kw, y, exp = load_golden("refdefault_am")
     plan = _plan(kw)
@@ -642,6 +648,35 @@ def test_change_tail_on_device(kwargs, gpu):
         # float64 recursion with poles close to the unit circle: fma contraction vs scipy's
         # evaluation order moves results by ~5e-9 relative; tolerance 1e-7 of the curve's maximum
         assert np.abs(got[i] - want).max() <= 1e-7 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("filt,kw", [
+    ("fir", dict(cutOff=[12.0], filtLen=6)), ("fir", dict(cutOff=[30.0], filtLen=2)),
+    ("fir", dict(cutOff=[20.0], filtLen=7, filtType="high")), ("fir", dict(cutOff=[5.0, 40.0], filtLen=8, filtType="band")),
+    ("sg", dict(cutOff=[12.0], filtLen=5, polyOrd=3)), ("sg", dict(cutOff=[12.0], filtLen=13, polyOrd=2)),
+    ("iir", dict(cutOff=[12.0], filtLen=6)),
+])
+def test_apply_filter_on_device(filt, kw, gpu):
+    """applyFilter (script/mfcc.py:29-135) on float64 curves that live on the GPU: every method stays there
+    ('iir' mm_sosfiltfilt_f64; 'fir' = filtfilt and 'sg' = savgol_filter(mode='interp') as banded operators
+    through mm_stencil_f64) and equals the reference's scipy call on the host; ragged lengths down to the
+    shortest scipy admits, a single curve, scipy's own error for a curve that is too short."""
+    from modulation_mfcc_amd import applyFilter
+    rng = np.random.default_rng(11)
+    sr = 200.0
+    n_min = 3 * kw["filtLen"] + 1 if filt == "fir" else (kw["filtLen"] if filt == "sg" else 40)
+    for n in (n_min, n_min + 1, 333, 1001):
+        x = rng.standard_normal((19, n)).cumsum(axis=1) + 3.0
+        want = np.stack([applyFilter(r, sr, filt=filt, **kw) for r in x])
+        got = applyFilter(_dev(x, gpu), sr, filt=filt, **kw)
+        assert got.is_cuda and got.shape == want.shape
+        tol = 1e-7 if filt == "iir" else 1e-12
+        assert np.abs(got.cpu().numpy() - want).max() <= tol * np.abs(want).max(), (n, np.abs(got.cpu().numpy() - want).max())
+    one = applyFilter(_dev(x[3], gpu), sr, filt=filt, **kw).cpu().numpy()
+    assert one.shape == (1001,) and np.abs(one - want[3]).max() <= 1e-7 * np.abs(want).max()
+    if filt == "fir":
+        with pytest.raises(ValueError, match="greater than padlen"):
+            applyFilter(_dev(x[:, :3 * kw["filtLen"]], gpu), sr, filt=filt, **kw)
 
 
 @pytest.mark.parametrize("kw", [

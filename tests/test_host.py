@@ -178,6 +178,40 @@ def test_resampler_quality(sr_in, sr_out):
         assert 20 * np.log10(np.abs(alias[mid]).max()) < -115.0
 
 
+def _stencil_numpy(st, y):
+    n = len(y)
+    out = np.empty(n)
+    for i in range(n):
+        if i < st["n_edge"]:
+            out[i] = np.dot(st["el"][i], y[:st["edge_w"]]) / st["den_e"]
+        elif i >= n - st["n_edge"]:
+            out[i] = np.dot(st["er"][i - (n - st["n_edge"])], y[n - st["edge_w"]:]) / st["den_e"]
+        else:
+            out[i] = sum(c * y[i + o] for c, o in zip(st["c"], st["off"])) / st["den_c"]
+    return out
+
+
+@pytest.mark.parametrize("n_taps,kind,cut", [(6, "lowpass", [12.0]), (2, "lowpass", [20.0]), (8, "lowpass", [30.0]),
+                                             (7, "highpass", [15.0]), (5, "bandpass", [8.0, 25.0])])
+def test_fir_filtfilt_stencil_on_the_host(n_taps, kind, cut):
+    """applyFilter(filt='fir') = scipy.signal.filtfilt(firwin taps, 1, x) as ONE banded operator
+    (filters.fir_filtfilt_stencil): applied with numpy it reproduces scipy's two-pass result to round-off,
+    including the odd-extension edges.  The kernel applies exactly this arithmetic (GPU test
+    test_fir_filter_on_device)."""
+    from modulation_mfcc_amd.filters import fir_filtfilt_stencil
+    taps = scipy.signal.firwin(n_taps, np.asarray(cut) / 50.0, window=("kaiser", 7.4), pass_zero=kind)
+    st = fir_filtfilt_stencil(taps)
+    assert len(st["c"]) <= 16 and st["n_edge"] <= 8 and st["edge_w"] <= 16
+    rng = np.random.default_rng(3)
+    for n in (3 * n_taps + 1, 60, 333):
+        x = rng.standard_normal(n).cumsum() + 5.0
+        want = scipy.signal.filtfilt(taps, 1, x)
+        got = _stencil_numpy(st, x)
+        assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0), (n, np.abs(got - want).max())
+    with pytest.raises(NotImplementedError):
+        fir_filtfilt_stencil(np.ones(9) / 9)
+
+
 @pytest.mark.parametrize("kw", [
     dict(method="gradient", difference=1), dict(method="gradient", difference=2),
     dict(method="sg", width=3, polyOrder=2, difference=1), dict(method="sg", width=7, polyOrder=3, difference=2),
@@ -197,16 +231,7 @@ def test_velocity_stencils_on_the_host(kw):
     assert len(st["c"]) <= 16 and st["n_edge"] <= 8 and st["edge_w"] <= 16
     y = x
     for _ in range(passes):
-        n = len(y)
-        out = np.empty(n)
-        for i in range(n):
-            if i < st["n_edge"]:
-                out[i] = np.dot(st["el"][i], y[:st["edge_w"]]) / st["den_e"]
-            elif i >= n - st["n_edge"]:
-                out[i] = np.dot(st["er"][i - (n - st["n_edge"])], y[n - st["edge_w"]:]) / st["den_e"]
-            else:
-                out[i] = sum(c * y[i + o] for c, o in zip(st["c"], st["off"])) / st["den_c"]
-        y = out
+        y = _stencil_numpy(st, y)
     if kw["method"] == "sg" and kw["difference"] == 0:
         want = scipy.signal.savgol_filter(x, kw["width"], kw["polyOrder"], deriv=0, mode="interp")
     else:
