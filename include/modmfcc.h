@@ -19,6 +19,9 @@
  *   mm_sosfiltfilt_f64     <- applyFilter(filt='iir') (script/mfcc.py:29-135): scipy sosfiltfilt on a batch
  *   mm_stencil_f64         <- get_velocity (script/calc.py:593-650): np.gradient / savgol_filter /
  *                             findiff derivative of a curve -- row N2
+ *   mm_rms_f32,
+ *   mm_hilbert_envelope    <- calculate_amplitude_envelope (script/calc.py:284-343): librosa.feature.rms /
+ *                             |scipy.signal.hilbert| -- row N3
  *   mm_pcm_decode_f32,
  *   mm_resample_f32        <- librosa.load(path, sr=sigSr, mono=False) (script/mfcc.py:284,373) -- row N4
  *   mm_build_window/mel/dct<- scipy.signal.get_window('hann'), librosa.filters.mel,
@@ -42,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 110 /* 0.2.0 */
+#define MM_VERSION 111 /* 0.2.1 */
 
 typedef enum mm_status {
   MM_OK = 0,
@@ -213,6 +216,22 @@ int mm_stencil_f64(const mm_stencil* st, const double* d_x, int64_t rows, int64_
 int64_t mm_rms_num_frames(int64_t n_samples, int32_t frame_length, int32_t hop_length, int32_t center);
 int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t audio_stride,
                int32_t frame_length, int32_t hop_length, int32_t center, float* d_rms, void* stream);
+
+/* Hilbert envelope (row N3): np.abs(scipy.signal.hilbert(x)) as called at script/calc.py:286 -- the DFT of the
+ * clip at its own length n (any integer 1 .. 2^24), negative frequencies zeroed, positive ones doubled, the
+ * inverse DFT, the magnitude -- for a batch of clips of one length.  Both DFTs are Bluestein chirp-z transforms
+ * over power-of-two Stockham FFTs of mm_hilbert_fft_size() points (n a power of two >= 16: the FFT itself), in
+ * the clips' own precision like scipy (dtype 0: float32 / complex64, 1: float64 / complex128).
+ * mm_hilbert_create allocates and fills the constant device tables on the current device (and synchronises);
+ * mm_hilbert_envelope is asynchronous on `stream`: d_x [rows][x_stride] -> d_env [rows][env_stride], rows <=
+ * 65535 per call, workspace = mm_hilbert_workspace_bytes(rows) = two [rows][fft_size] complex buffers. */
+typedef struct mm_hilbert mm_hilbert;
+int mm_hilbert_create(int64_t n, int32_t dtype, mm_hilbert** out);
+void mm_hilbert_destroy(mm_hilbert* h);
+int64_t mm_hilbert_fft_size(const mm_hilbert* h);
+size_t mm_hilbert_workspace_bytes(const mm_hilbert* h, int64_t rows);
+int mm_hilbert_envelope(mm_hilbert* h, const void* d_x, int64_t rows, int64_t x_stride, void* d_env,
+                        int64_t env_stride, void* d_workspace, size_t ws_bytes, void* stream);
 
 /* Input side (row N4): what librosa.load(path, sr=sigSr, mono=False) does before the hot path
  * (script/mfcc.py:284,373).

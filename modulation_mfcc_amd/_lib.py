@@ -105,6 +105,11 @@ PROTOTYPES = {
     "mm_change_workspace_bytes": (C.c_size_t, [_vp, _i64, _i64]),
     "mm_rms_num_frames": (_i64, [_i64, C.c_int32, C.c_int32, C.c_int32]),
     "mm_rms_f32": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    "mm_hilbert_create": (C.c_int, [_i64, C.c_int32, C.POINTER(_vp)]),
+    "mm_hilbert_destroy": (None, [_vp]),
+    "mm_hilbert_fft_size": (_i64, [_vp]),
+    "mm_hilbert_workspace_bytes": (C.c_size_t, [_vp, _i64]),
+    "mm_hilbert_envelope": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.c_size_t, _vp]),
     "mm_pcm_decode_f32": (C.c_int, [_vp, C.c_int32, C.c_int32, _i64, _vp, _i64, _vp]),
     "mm_resample_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, _i64, _vp, _i64, _vp]),
     "mm_devcopy_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
@@ -137,7 +142,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError when the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.mm_version() < 110:
+    if lib.mm_version() < 111:
         raise ImportError("libmodmfcc.so is older than the Python binding; rebuild it")
     _lib = lib
     return lib

@@ -20,28 +20,71 @@ def _is_device_tensor(x):
     return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
 
 
+_HILBERT_PLANS = {}
+HILBERT_WS_BYTES = 4 << 30      # workspace bound of one mm_hilbert_envelope call: batches are cut to fit
+
+
+class _HilbertPlan:
+    """Owner of one mm_hilbert handle (constant chirp / twiddle tables of one clip length on one device)."""
+
+    def __init__(self, n, dtype_code, device):
+        import ctypes as C
+        import torch
+        from . import _lib
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self._lib.mm_hilbert_create(n, dtype_code, C.byref(h)), "mm_hilbert_create")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self._lib.mm_hilbert_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def hilbert_envelope_batch(x):
     """|scipy.signal.hilbert(x)| along the last axis of a CUDA(HIP) tensor ([n] or [B, n], float32 or float64)
-    on the device, in scipy's arithmetic: FFT of length N = len(x) in the input's precision, negative
-    frequencies zeroed / positive ones doubled, inverse FFT, magnitude (script/calc.py:286).
+    on the device, in scipy's arithmetic: DFT of length N = len(x) in the input's precision, negative
+    frequencies zeroed / positive ones doubled, inverse DFT, magnitude (script/calc.py:286).
 
-    N is the clip length, an arbitrary integer (160 000 = 2^8 * 5^4 for a 10 s clip): this is the ONE place where
-    the build calls a library transform -- rocFFT through ``torch.fft`` -- instead of its own kernels, whose
-    register radix-16 FFTs cover powers of two up to 8192 (frames, trajectories), not a mixed-radix / Bluestein
-    transform of a whole clip.  The spectrum mask and the magnitude are plain elementwise device work."""
+    N is the clip length, an arbitrary integer (160 000 = 2^8 * 5^4 for a 10 s clip): both DFTs are Bluestein
+    chirp-z transforms over the library's own power-of-two Stockham FFT (mm_hilbert_envelope,
+    csrc/mm_hilbert.hip.inc); the constant tables of a length are built once and kept."""
+    import ctypes as C
     import torch
+    from . import _lib
     if not (_is_device_tensor(x) and x.dtype in (torch.float32, torch.float64)):
         raise TypeError("x must be a float32 / float64 CUDA(HIP) tensor")
-    n = x.shape[-1]
-    X = torch.fft.fft(x, dim=-1)
-    h = torch.zeros(n, dtype=x.dtype, device=x.device)
-    if n % 2 == 0:
-        h[0] = h[n // 2] = 1
-        h[1:n // 2] = 2
-    else:
-        h[0] = 1
-        h[1:(n + 1) // 2] = 2
-    return torch.fft.ifft(X * h, dim=-1).abs()
+    squeeze = x.dim() == 1
+    x2 = x.unsqueeze(0) if squeeze else x
+    if x2.dim() != 2:
+        raise ValueError("x must be [n] or [B, n]")
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    rows, n = x2.shape
+    out = torch.empty((rows, n), dtype=x.dtype, device=x.device)
+    if n == 0 or rows == 0:
+        return out[0] if squeeze else out
+    code = 0 if x.dtype == torch.float32 else 1
+    key = (n, code, str(x.device))
+    if key not in _HILBERT_PLANS:
+        _HILBERT_PLANS[key] = _HilbertPlan(n, code, x.device)
+    plan = _HILBERT_PLANS[key]
+    lib = _lib.load()
+    per_row = int(lib.mm_hilbert_workspace_bytes(plan.h, 1))
+    chunk = max(1, min(rows, 65535, HILBERT_WS_BYTES // per_row))
+    ws = torch.empty(chunk * per_row, dtype=torch.uint8, device=x.device)
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    with torch.cuda.device(x.device):
+        for r0 in range(0, rows, chunk):
+            r = min(chunk, rows - r0)
+            _lib.check(lib.mm_hilbert_envelope(plan.h, x2[r0:].data_ptr(), r, x2.stride(0), out[r0:].data_ptr(), n,
+                                               ws.data_ptr(), ws.numel(), stream), "mm_hilbert_envelope")
+    return out[0] if squeeze else out
 
 
 def amplitude_envelope_batch(x, sr, *, method: str = "RMS", winLen: float = 0.1, hopLen: float = 0.01,

@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <new>
 
 #include "mm_internal.h"
 
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_logmel16s.hip.inc"
 #include "mm_logmel12m.hip.inc"
 #include "mm_wpf.hip.inc"
+#include "mm_hilbert.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 // plan

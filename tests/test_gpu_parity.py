@@ -802,6 +802,46 @@ def test_rms_frames_on_device(n, fl, hop, center, gpu):
         np.testing.assert_allclose(got[i], want, rtol=2e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hilbert_envelope_on_device(dt, gpu):
+    """Row N3: |scipy.signal.hilbert(x)| (script/calc.py:286) through mm_hilbert_envelope -- the library's own
+    Stockham FFT at the clip's own length when that is 2^a 3^b 5^c 7^d, Bluestein chirp-z transforms over a
+    power-of-two FFT otherwise -- against scipy in float64: lengths 1 .. 480 000 (every pass radix 2 .. 49 alone,
+    first and later; primes; products), batches, a strided batch, a batch cut into workspace-bounded calls."""
+    import scipy.signal
+    from modulation_mfcc_amd import calc
+    rng = np.random.default_rng(8)
+    tol = 2e-5 if dt == np.float32 else 1e-11
+    for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 15, 16, 17, 21, 22, 25, 27, 31, 32, 35, 45, 49, 63, 64, 75, 100, 105,
+              121, 125, 127, 128, 147, 225, 245, 256, 257, 343, 512, 625, 1000, 1024, 2048, 2401, 4000, 4001, 4096,
+              8191, 8192, 12345, 16807, 44100, 65536, 99991, 117649, 160000, 441000, 480000):
+        rows = 3 if n > 20000 else 5
+        x = (rng.standard_normal((rows, n)) * np.linspace(0.2, 1.0, n)[None, :]).astype(dt)
+        want = np.abs(scipy.signal.hilbert(x.astype(np.float64), axis=1))
+        got = calc.hilbert_envelope_batch(_dev(x, gpu))
+        assert got.is_cuda and got.shape == want.shape and got.cpu().numpy().dtype == dt
+        err = np.abs(got.cpu().numpy() - want).max()
+        assert err <= tol * max(want.max(), 1e-30), (n, err, want.max())
+    # a strided view (every other row of a bigger batch) and a single clip
+    big = _dev(rng.standard_normal((6, 3001)).astype(dt), gpu)
+    got = calc.hilbert_envelope_batch(big[::2]).cpu().numpy()
+    want = np.abs(scipy.signal.hilbert(big[::2].cpu().numpy().astype(np.float64), axis=1))
+    assert np.abs(got - want).max() <= tol * want.max()
+    one = calc.hilbert_envelope_batch(big[1]).cpu().numpy()
+    assert one.shape == (3001,)
+    assert np.abs(one - np.abs(scipy.signal.hilbert(big[1].cpu().numpy().astype(np.float64)))).max() <= tol * want.max()
+    # more rows than one workspace-bounded call takes
+    old = calc.HILBERT_WS_BYTES
+    try:
+        calc.HILBERT_WS_BYTES = 3 * 2 * 8192 * (8 if dt == np.float32 else 16)      # three rows per call
+        x = rng.standard_normal((8, 3000)).astype(dt)
+        got = calc.hilbert_envelope_batch(_dev(x, gpu)).cpu().numpy()
+    finally:
+        calc.HILBERT_WS_BYTES = old
+    want = np.abs(scipy.signal.hilbert(x.astype(np.float64), axis=1))
+    assert np.abs(got - want).max() <= tol * want.max()
+
+
 def test_amplitude_envelope_on_device(gpu):
     """Row N3, drop-in: calculate_amplitude_envelope (script/calc.py:221-343) computes its envelope on the GPU
     -- 'RMS' through mm_rms_f32, 'Hilb' through a device FFT of the clip length -- for numpy input (numpy out,
