@@ -135,18 +135,27 @@ def cpu_baseline(kw, n, with_mod, budget_s=12.0):
                       f"1 thread, {dt:.1f} s wall, {busy:.0f} core-seconds in the path"}
 
 
+EVENT_EVERY = 4      # dominant-kernel HIP events on every 4th timed step
+
+
 def time_steps(torch, plan, fn, steps, warmup, stages, sync=None):
-    """warmup untimed + `steps` timed calls of fn; HIP events around `stages` only inside the timed region,
-    the other stages from a short pass afterwards.  Returns (seconds, {stage: (ms_sum, launches)})."""
+    """warmup untimed + `steps` timed calls of fn; HIP events around `stages` only inside the timed region --
+    and only on every EVENT_EVERY-th step there (an event pair costs the stream two barrier packets, ~6 us each:
+    rocprofv3 shows them as gaps on both sides of the kernel) -- the other stages from a short pass afterwards.
+    Returns (seconds, {stage: (ms_sum, launches)})."""
     for _ in range(warmup):
         fn()
     if sync:
         sync()
     torch.cuda.synchronize()
-    plan.timing_enable(True, stages=stages)
+    every = max(1, min(EVENT_EVERY, steps // 5))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        if i % every == 0:
+            plan.timing_enable(True, stages=stages)
+        elif i % every == 1 or every == 1:
+            plan.timing_enable(False)
         fn()
     if sync:
         sync()
@@ -183,7 +192,7 @@ def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=No
     out = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
            "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_frame": alg[dom],
-           "avg_launch_ms": per_stage[dom]["avg_ms"]}
+           "avg_launch_ms": per_stage[dom]["avg_ms"], "launches_timed": per_stage[dom]["launches"]}
     if dom == "logmel":
         # for information: the fused kernel is issue / LDS bound, not HBM bound -- its
         # algorithmic flops (rFFT 2.5 N log2 N + power + sparse mel + log + DCT) against the FP32 vector peak
