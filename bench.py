@@ -176,10 +176,12 @@ def time_steps(torch, plan, fn, steps, warmup, stages, sync=None):
     return dt, stage
 
 
-def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=None):
+def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=None, fused_tail=False):
     alg = {
-        # unique audio in + log-mel out (+ the unclamped MFCC rows where the kernel also applies the DCT)
-        "logmel": 4 * cfg.hop_length + 4 * cfg.n_mels + (4 * cfg.n_mfcc if fused_dct else 0),
+        # unique audio in + log-mel out (+ the unclamped MFCC rows where the kernel also applies the DCT, + the
+        # modulation-spectrum rows where the whole tail runs in the launch)
+        "logmel": 4 * cfg.hop_length + 4 * cfg.n_mels + (4 * cfg.n_mfcc if fused_dct else 0)
+                  + (8 * (n_mod // 2 + 1) * cfg.n_mfcc / T if fused_tail else 0),
         "dct": 4 * cfg.n_mels + 4 * cfg.n_mfcc,            # log-mel in + MFCC out
         "modspec": (4 * T + 8 * (n_mod // 2 + 1)) * cfg.n_mfcc / T if with_mod else 0,
     }
@@ -215,6 +217,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c4 / rFFT-stage passes (profiling runs)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernels")
+    ap.add_argument("--no-fuse-tail", action="store_true", help="separate launches for the clamp fix-up and the trajectory rFFT: development A/B")
     ap.add_argument("--variant", default=None, help="pin a fused-kernel variant (m12, w16s, w16, w8, wpf): development A/B")
     ap.add_argument("--gather", default="mfcc", choices=["mfcc", "full"],
                     help="N > 1: 'mfcc' gathers the MFCC slab and the root computes the modulation spectrum of the "
@@ -273,6 +276,8 @@ def main():
             plan.force_generic(True)
         if a.variant:
             plan.set_variant(a.variant)
+        if a.no_fuse_tail:
+            plan.set_fuse_tail(False)
         audio = synth_batch(torch, dev, b * c, n, cfg.sr, seed0=1000 * rank)
         if c > 1:                      # [B, ch, n]: the rows the kernels see are the channels, stride n
             audio = audio.view(b, c, n)
@@ -308,9 +313,10 @@ def main():
         def step():
             slab = pg.acquire() if pg else slab1
             mfcc_out, mod_out = lay.views(slab)
-            plan.mfcc(rows, out=mfcc_out)
             if with_mod and not mod_on_root:
-                plan.modspec(mfcc_out, out=mod_out)
+                plan.mfcc_modspec(rows, out=mfcc_out, out_mod=mod_out)    # one launch where the plan can (fused tail)
+            else:
+                plan.mfcc(rows, out=mfcc_out)
             if pg:
                 pg.submit(post=root_modspec if mod_on_root else None)
 
@@ -362,7 +368,10 @@ def main():
         per_stage = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in stage.items()}
         res["kernels_ms"] = {k: round(v["avg_ms"], 4) for k, v in per_stage.items()}
         key = {"radix16-w16s": "logmel512s", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(plan.kernel_path)
-        rl = roofline_of(cfg, R, T, n_mod, with_mod, per_stage, fused, key)
+        ftail = bool(with_mod and not mod_on_root and plan.fused_tail(R, n))
+        res["config"]["launches_per_step"] = 1 if ftail else (len(per_stage) if per_stage else None)
+        res["config"]["fused_tail"] = ftail
+        rl = roofline_of(cfg, R, T, n_mod, with_mod, per_stage, fused, key, fused_tail=ftail)
         if rl:
             res["roofline"] = rl
 

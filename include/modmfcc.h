@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 111 /* 0.2.1 */
+#define MM_VERSION 112 /* 0.2.2 */
 
 typedef enum mm_status {
   MM_OK = 0,
@@ -137,6 +137,13 @@ int mm_plan_fused_dct(const mm_plan* plan);
 /* on = 0: always run the separate clamp + DCT kernel (A/B measurements, cross-checks); returns the
  * previous setting.  Default on. */
 int mm_plan_set_fuse_dct(mm_plan* plan, int on);
+/* mm_mfcc_modspec_f32 in ONE launch (whole clips per workgroup: the clip maximum / minimum never leave it, the
+ * clamp fix-up and the trajectory rFFT run inside the tile kernel)?  1 when the n_fft 512 staged-sample kernel
+ * with its fused DCT takes the call, the trajectory length is 512 or 1024 and `batch` clips spread over the
+ * compute units within 4 %; 0 = the separate launches.  mm_plan_set_fuse_tail(0) pins the separate launches
+ * (A/B measurements, cross-checks; returns the previous setting; default on). */
+int mm_plan_fused_tail(const mm_plan* plan, int64_t batch, int64_t n_samples);
+int mm_plan_set_fuse_tail(mm_plan* plan, int on);
 /* force the generic kernels (debug / cross-check); returns previous value */
 int mm_plan_force_generic(mm_plan* plan, int on);
 /* pin one of the variants above (1..5) for the calls it can take, 0 = automatic choice; returns the
@@ -169,6 +176,13 @@ int mm_rfft_f32(mm_plan* plan, const float* d_in, int64_t rows, int64_t in_len,
 /* d_mfcc [batch][n_mfcc][n_frames] -> complex64 [batch][n_mfcc][n_mod/2+1]                   */
 int mm_modspec_f32(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_t n_frames,
                    float* d_modspec, void* stream);
+
+/* Rows A1-A6 + A8 in one call: d_mfcc as mm_mfcc_f32 (bit for bit), d_modspec as mm_modspec_f32 of it (to
+ * float32 round-off: the in-kernel transform is a second instantiation of the same code); one kernel launch
+ * where mm_plan_fused_tail() says so, the two calls' launches otherwise.  Workspace: mm_workspace_bytes(). */
+int mm_mfcc_modspec_f32(mm_plan* plan, const float* d_audio, int64_t batch, int64_t n_samples,
+                        int64_t audio_stride, float* d_mfcc, float* d_modspec, void* d_workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* MFCC-change tail (script/mfcc.py:392-427, outFilter 'iir' low-pass or None): d_mfcc [batch][n_mfcc]
  * [n_frames] f32 -> d_change [batch][n_frames] f64.  diff_method 0 = np.gradient (diffMethod='grad',

@@ -89,6 +89,9 @@ PROTOTYPES = {
     "mm_plan_kernel_path": (C.c_int, [_vp]),
     "mm_plan_fused_dct": (C.c_int, [_vp]),
     "mm_plan_set_fuse_dct": (C.c_int, [_vp, C.c_int]),
+    "mm_plan_fused_tail": (C.c_int, [_vp, _i64, _i64]),
+    "mm_plan_set_fuse_tail": (C.c_int, [_vp, C.c_int]),
+    "mm_mfcc_modspec_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, C.c_size_t, _vp]),
     "mm_plan_force_generic": (C.c_int, [_vp, C.c_int]),
     "mm_plan_set_variant": (C.c_int, [_vp, C.c_int]),
     "mm_workspace_bytes": (C.c_size_t, [_vp, _i64, _i64]),
@@ -142,7 +145,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError when the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.mm_version() < 111:
+    if lib.mm_version() < 112:
         raise ImportError("libmodmfcc.so is older than the Python binding; rebuild it")
     _lib = lib
     return lib

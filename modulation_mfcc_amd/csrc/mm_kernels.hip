@@ -332,6 +332,8 @@ struct mm_plan {
   size_t dctfm_lds;
   int variant;                     // mm_plan_set_variant: 0 = automatic
   int no_fuse;                     // mm_plan_set_fuse_dct(0): always run the separate clamp + DCT kernel
+  int no_fuse_tail;                // mm_plan_set_fuse_tail(0): mm_mfcc_modspec_f32 always runs its separate launches
+  unsigned s16f_red_off;           // clip mode: LDS offset of the per-wave clip max / min slots
 
   float* d_window_e;                       // n_fft < 512 embedded in the 512-point kernels: window centred in 512
   int embed;                               // 512 / n_fft for such plans, else 1
@@ -592,7 +594,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0;
-  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->d_dctfm_a = nullptr;
+  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 0; p->s16f_red_off = 0; p->d_dctfm_a = nullptr;
   p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
@@ -754,7 +756,8 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
           const size_t tab_end = (size_t)(p->s16_nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tabf.size() * 4;
           p->s16f_lt_off = (unsigned)align_up(tab_end, 16);
           p->s16f_dcta_off = p->s16f_lt_off + 2u * (unsigned)lt_rows * 320u;
-          p->s16f_lds_bytes = (size_t)p->s16f_dcta_off + dcta.size() * 4;
+          p->s16f_red_off = (unsigned)align_up((size_t)p->s16f_dcta_off + dcta.size() * 4, 16);
+          p->s16f_lds_bytes = (size_t)p->s16f_red_off + 2 * 16 * 8;
           if (p->s16f_lds_bytes <= MM_LM_LDS_MAX &&
               upload(&p->d_s16f_tab, tabf.data(), tabf.size() * 4) == MM_OK &&
               upload(&p->d_s16f_part, partf.data(), partf.size() * 4) == MM_OK &&
@@ -915,6 +918,9 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
 extern "C" int mm_debug_stamps(unsigned int* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm_stamp_acc), sizeof(unsigned int) * 256) == hipSuccess ? 0 : -1;
 }
+extern "C" int mm_debug_fin_stamps(unsigned int* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm_fin_acc), sizeof(unsigned int) * 128) == hipSuccess ? 0 : -1;
+}
 #endif
 
 int mm_plan_destroy(mm_plan* p) {
@@ -983,6 +989,13 @@ int mm_plan_set_fuse_dct(mm_plan* p, int on) {
   return prev;
 }
 
+int mm_plan_set_fuse_tail(mm_plan* p, int on) {
+  if (!p) return MM_ERR_INVALID_ARG;
+  const int prev = !p->no_fuse_tail;
+  p->no_fuse_tail = on ? 0 : 1;
+  return prev;
+}
+
 int mm_plan_set_variant(mm_plan* p, int variant) {
   if (!p || variant < 0 || variant > MM_K_M12) return MM_ERR_INVALID_ARG;
   const int prev = p->variant;
@@ -1014,7 +1027,22 @@ struct StftOut {
   bool frame_major = false;    // the caller accepts log-mel rows laid out [B][T][n_mels]
   bool is_fm = false;          // out: that layout was written
   bool fused_dct = false;      // out: mfcc holds the unclamped DCT
+  float* mod = nullptr;        // in: modulation-spectrum output wanted from the same launch (clip mode)
+  int n_mod = 0;
+  bool fused_tail = false;     // out: clamp fix-up and trajectory rFFT were part of the launch (no keys used)
 };
+
+// Clip mode of the staged-sample kernel (whole clips per workgroup, tail fused in): the trajectory length must be
+// one the in-kernel rFFT covers, and the clips must spread evenly -- a workgroup that gets one clip more than the
+// others sets the launch time, so the uneven case stays on the tile-granular split + separate launches.
+static bool s16_clip_mode_ok(const mm_plan* p, int64_t batch, int n_mod) {
+  if (p->no_fuse_tail || !(n_mod == 512 || n_mod == 1024)) return false;
+  if (p->s16f_lds_bytes + MM_S16_FIN_TAB_BYTES > MM_LM_LDS_MAX) return false;     // no room for the rFFT twiddles
+  const int64_t g = p->num_cus;
+  if (batch < g) return false;
+  const int64_t per = (batch + g - 1) / g;
+  return per * g * 100 <= batch * 104;          // at most 4 % of idle workgroup time
+}
 
 static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch, int64_t n_samples,
                        int64_t stride, StftOut& o, hipStream_t st) {
@@ -1089,10 +1117,11 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.out_power = o.power;
     q.out_mfcc = nullptr; q.key_nmin = nullptr; q.dct_a = nullptr; q.n_mfcc = 0; q.dct_nk = q.dct_kb = q.lt_rows = 0;
     q.lt_off = q.dcta_off = 0; q.dct_roles = ~0ull;
+    q.out_mod = nullptr; q.dct_t = nullptr; q.n_mod = q.dct_kp = 0; q.top_db = -1.0f; q.red_off = 0;
     q.lane_tab = p->d_lane_tab;
     q.preemph = p->cfg.preemph;
     if (q.n_tiles > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-    const int64_t grid = q.n_tiles < p->num_cus ? q.n_tiles : p->num_cus;
+    int64_t grid = q.n_tiles < p->num_cus ? q.n_tiles : p->num_cus;
     if (kern == MM_K_W16S || kern == MM_K_W16) {
       q.mel_tab = (const float4*)p->d_w16_tab; q.n_runs = p->w16_n_runs; q.n_tab16 = p->w16_n_tab16;
       q.wave_part = p->d_w16_part;
@@ -1111,6 +1140,14 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
           q.lt_off = p->s16f_lt_off; q.dcta_off = p->s16f_dcta_off; q.dct_roles = p->s16f_roles;
           if (p->cfg.top_db < 0.0f) q.out_logmel = nullptr;      // the rows only feed the clamp fix-up
           lds = p->s16f_lds_bytes;
+          q.red_off = p->s16f_red_off;
+          if (o.mod != nullptr && s16_clip_mode_ok(p, batch, o.n_mod)) {
+            // whole clips per workgroup: extremes, clamp fix-up and trajectory rFFT inside the launch
+            o.fused_tail = true;
+            q.out_mod = (float2*)o.mod; q.n_mod = o.n_mod; q.dct_t = p->d_dct_t; q.dct_kp = p->kp; q.top_db = p->cfg.top_db;
+            grid = batch < p->num_cus ? batch : p->num_cus;
+            lds += MM_S16_FIN_TAB_BYTES;
+          }
         }
         launch_s16(mode, p->s16_nr, pre, odd, unal, dim3((unsigned)grid), lds, st, q);
         HIP_TRY(hipGetLastError());
@@ -1303,6 +1340,43 @@ int mm_modspec_f32(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_fra
   hipStream_t st = (hipStream_t)stream;
   StageTimer tm(p, MM_STAGE_MODSPEC, st);
   return launch_rfft(p, d_mfcc, batch * p->cfg.n_mfcc, n_frames, n_frames, n, d_out, st);
+}
+
+int mm_mfcc_modspec_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_samples, int64_t stride,
+                        float* d_mfcc, float* d_modspec, void* d_ws, size_t ws_bytes, void* stream) {
+  int rc = check_audio_args(p, d_audio, batch, n_samples, stride);
+  if (rc || !d_mfcc || !d_modspec || !d_ws) return rc ? rc : MM_ERR_INVALID_ARG;
+  if (ws_bytes < mm_workspace_bytes(p, batch, n_samples)) return MM_ERR_WORKSPACE;
+  const int64_t T = mm_num_frames(&p->cfg, n_samples);
+  const int n_mod = mm_mod_fft_len(&p->cfg, T);
+  if (n_mod < 0) return n_mod;
+  hipStream_t st = (hipStream_t)stream;
+  if (choose_kernel(p, 1, true, d_audio, n_samples, stride) == MM_K_W16S && p->s16f_ok && !p->no_fuse &&
+      s16_clip_mode_ok(p, batch, n_mod)) {
+    // ONE launch: a workgroup owns whole clips, so the clip extremes never leave it (no key arrays, no memset),
+    // the clamped DCT of a clip that needs it and the trajectory rFFT of every finished clip run in the kernel
+    StageTimer tm(p, MM_STAGE_LOGMEL, st);
+    StftOut o;
+    int* keys = (int*)((char*)d_ws + align_up((size_t)batch * p->cfg.n_mels * T * 4, 256));
+    o.logmel = (float*)d_ws; o.key_max = keys; o.key_nmin = keys + batch; o.mfcc = d_mfcc; o.frame_major = true;
+    o.mod = d_modspec; o.n_mod = n_mod;
+    rc = launch_stft(p, 1, d_audio, batch, n_samples, stride, o, st);
+    if (rc) return rc;
+    if (o.fused_tail) return MM_OK;
+    return MM_ERR_UNSUPPORTED;       // not reached: the predicate above is the one launch_stft applies
+  }
+  rc = mm_mfcc_f32(p, d_audio, batch, n_samples, stride, d_mfcc, d_ws, ws_bytes, stream);
+  if (rc) return rc;
+  return mm_modspec_f32(p, d_mfcc, batch, T, d_modspec, stream);
+}
+
+int mm_plan_fused_tail(const mm_plan* p, int64_t batch, int64_t n_samples) {
+  if (!p || batch < 1 || n_samples < 1) return MM_ERR_INVALID_ARG;
+  const int64_t T = mm_num_frames(&p->cfg, n_samples);
+  const int n_mod = mm_mod_fft_len(&p->cfg, T);
+  if (n_mod < 0) return 0;
+  return (choose_kernel(p, 1, false, nullptr, 0, 0) == MM_K_W16S && n_samples >= 4 && p->s16f_ok && !p->no_fuse &&
+          s16_clip_mode_ok(p, batch, n_mod)) ? 1 : 0;
 }
 
 // scipy.signal.sosfilt_zi + the padlen rule of sosfiltfilt, host side

@@ -236,6 +236,14 @@ class MfccPlan:
             _lib.check(prev, "mm_plan_set_variant")
         return "auto" if prev == 0 else KERNEL_PATHS[prev]
 
+    def fused_tail(self, batch, n_samples):
+        """True when mfcc_modspec() of `batch` clips of `n_samples` runs as ONE launch (mm_plan_fused_tail)."""
+        return bool(self._lib.mm_plan_fused_tail(self._h, int(batch), int(n_samples)))
+
+    def set_fuse_tail(self, on=True):
+        """Pin the separate launches for mfcc_modspec() (on=False); returns the previous setting."""
+        return bool(self._lib.mm_plan_set_fuse_tail(self._h, 1 if on else 0))
+
     def force_generic(self, on=True):
         return self._lib.mm_plan_force_generic(self._h, 1 if on else 0)
 
@@ -256,6 +264,30 @@ class MfccPlan:
                                              out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                        "mm_mfcc_f32")
         return out
+
+    def mfcc_modspec(self, audio, out=None, out_mod=None):
+        """[B, n] float32 device tensor -> (MFCC [B, n_mfcc, T] float32, modulation spectrum complex64
+        [B, n_mfcc, n_mod/2+1]): mfcc() followed by modspec() (MFCC bit for bit, spectrum to float32 round-off), in
+        one launch where the plan can (fused_tail())."""
+        torch = _torch()
+        audio = self._check_audio(audio)
+        B, n = audio.shape
+        T = self.cfg.num_frames(n)
+        nm = self.cfg.mod_fft_len(T)
+        if out is None:
+            out = torch.empty((B, self.cfg.n_mfcc, T), dtype=torch.float32, device=self.device)
+        else:
+            self._check_out(out, (B, self.cfg.n_mfcc, T), torch.float32, "mfcc")
+        if out_mod is None:
+            out_mod = torch.empty((B, self.cfg.n_mfcc, nm // 2 + 1), dtype=torch.complex64, device=self.device)
+        else:
+            self._check_out(out_mod, (B, self.cfg.n_mfcc, nm // 2 + 1), torch.complex64, "modspec")
+        ws = self.workspace(B, n)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mm_mfcc_modspec_f32(self._h, audio.data_ptr(), B, n, audio.stride(0), out.data_ptr(),
+                                                     out_mod.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                       "mm_mfcc_modspec_f32")
+        return out, out_mod
 
     def logmel(self, audio):
         """Unclamped 10*log10(max(amin, mel)) [B, n_mels, T] and the per-clip max [B]."""

@@ -545,6 +545,56 @@ def test_full_size_properties(gpu):
     assert torch.allclose(e_time, e_freq, rtol=1e-4)
 
 
+@pytest.mark.parametrize("extra,n,batches", [
+    (dict(), 160000, (256, 512, 300)),                        # T 1001 -> n_mod 1024; 300 clips: uneven -> separate launches
+    (dict(), 48000, (256, 1024)),                             # T 301 -> n_mod 512
+    (dict(top_db=-1.0), 160000, (256,)),                      # no clamp
+    (dict(preemph=0.97, hop_length=161), 48003, (256,)),      # odd hop, unaligned length, pre-emphasis
+    (dict(n_mfcc=16), 160000, (256,)),                        # more rows than one pass of the rFFT waves takes
+    (dict(n_mfcc=20, n_mels=64), 160000, (256,)),             # no fused DCT for this shape -> separate launches
+])
+def test_fused_tail_matches_separate_launches(extra, n, batches, gpu):
+    """mm_mfcc_modspec_f32: where the plan runs it as ONE launch (whole clips per workgroup, clip extremes kept in
+    the workgroup, clamp fix-up and trajectory rFFT inside the tile kernel) the results equal the separate
+    launches' -- MFCC bit for bit, including clips that clamp; modulation spectrum to float32 round-off -- spot
+    clips against the oracle; the uneven batch takes the separate launches and says so."""
+    import torch
+    kw, _, _ = load_golden("c1_am")
+    kw = dict(kw, **extra)
+    plan = _plan(kw)
+    g = torch.Generator(device=gpu).manual_seed(3)
+    for B in batches:
+        audio = 0.1 * torch.randn((B, n), generator=g, device=gpu)
+        audio[::3, n // 2:] *= 1e-6                                          # quiet tails: these clips clamp
+        audio[1::7] = 0.0
+        audio[1::7, 1000] = 1.0                                              # an impulse in silence
+        even = B % 256 == 0
+        assert plan.fused_tail(B, n) == (even and plan.kernel_path == "radix16-w16s" and plan.fused_dct)
+        m1, s1 = plan.mfcc_modspec(audio)
+        prev = plan.set_fuse_tail(False)
+        try:
+            assert not plan.fused_tail(B, n)
+            m0, s0 = plan.mfcc_modspec(audio)
+        finally:
+            plan.set_fuse_tail(prev)
+        m2 = plan.mfcc(audio)
+        s2 = plan.modspec(m2)
+        assert torch.equal(m0, m2) and torch.equal(torch.view_as_real(s0), torch.view_as_real(s2))
+        assert torch.equal(m1, m0), float((m1 - m0).abs().max())
+        # the in-kernel trajectory rFFT is a second instantiation of the same source: the compiler contracts its
+        # multiply-adds differently, so the spectra agree to float32 round-off (1 ulp of the row maximum), not bitwise
+        err = (torch.view_as_real(s1) - torch.view_as_real(s0)).abs().amax(dim=(2, 3))
+        scale = torch.view_as_real(s0).abs().amax(dim=(2, 3))
+        assert bool((err <= 4e-7 * scale + 1e-30).all()), float((err / (scale + 1e-30)).max())
+        ocfg = O.OracleConfig(**dict(kw, top_db=None if kw.get("top_db", 80.0) < 0 else kw.get("top_db", 80.0)))
+        for i in (0, 1, B - 1):
+            mfcc_close(m1[i].cpu().numpy(), O.mfcc(audio[i].cpu().numpy(), ocfg), f"B={B} clip {i}")
+    if kw.get("top_db", 80.0) >= 0:
+        # the clamp did bite in the quiet-tail clips (otherwise this test would not cover the fix-up)
+        lm, mx = plan.logmel(audio[:1])
+        assert float(lm.min()) < float(mx[0]) - 80.0
+
+
 def test_full_size_c4_stereo(gpu):
     """BASELINE configs[3] at full size: a [512, 2, 480000] stereo tensor (48 kHz, 10 s), n_fft 2048 / 80 mel
     / 40 MFCC.  Each channel goes through the STRIDED-row path (audio[:, ch, :], row stride 2 n -- the
