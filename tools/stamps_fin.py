@@ -1,6 +1,6 @@
 """dev helper: like tools/stamps.py for the clip-mode finalisation (s16_finalize): build with -DMM_STAMP into
 ../libmodmfcc_stamp.so, MODMFCC_LIB=that; prints cycles per call (workgroup 0, 4 calls per launch), per wave:
-entry barrier | extremes (+ fix-up) | trajectory rFFT | exit barrier"""
+row loads arrived | DFT-16 #1 + twiddles + exchange | DFT-16 #2 (+ radix-2) | split + stores issued  (waves 0-6)"""
 import sys, ctypes, os
 sys.path.insert(0, '.')
 import numpy as np, torch
