@@ -20,9 +20,7 @@ def modspec_batch(mfcc, cfg: MfccConfig, out=None):
 
 def mfcc_modspec_batch(audio, cfg: MfccConfig, mfcc_out=None, mod_out=None):
     """The whole hot path: MFCC and its modulation spectrum."""
-    plan = get_plan(cfg)
-    m = plan.mfcc(audio, out=mfcc_out)
-    return m, plan.modspec(m, out=mod_out)
+    return get_plan(cfg).mfcc_modspec(audio, out=mfcc_out, out_mod=mod_out)     # one launch where the plan can
 
 
 def rfft_batch(rows, n: int, cfg: MfccConfig = None, out=None):

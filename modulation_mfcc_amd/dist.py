@@ -184,9 +184,10 @@ def mfcc_modspec_sharded(audio_all_or_local, cfg: MfccConfig, *, with_modspec=Tr
             from .plan import get_plan
             plan = get_plan(cfg)
             m, ms = lay.views(slab)
-            plan.mfcc(local, out=m[:local.shape[0]])
-            if send_mod:
-                plan.modspec(m[:local.shape[0]], out=ms[:local.shape[0]])
+            if send_mod:     # one launch where the plan can (fused tail)
+                plan.mfcc_modspec(local, out=m[:local.shape[0]], out_mod=ms[:local.shape[0]])
+            else:
+                plan.mfcc(local, out=m[:local.shape[0]])
         else:
             compute(local, lay_local, lay, slab)
     got = gather_slabs(slab, dst=dst, group=group)
