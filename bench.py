@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c4 / rFFT-stage passes (profiling runs)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernels")
-    ap.add_argument("--no-fuse-tail", action="store_true", help="separate launches for the clamp fix-up and the trajectory rFFT: development A/B")
+    ap.add_argument("--fuse-tail", action="store_true", help="opt-in: clamp fix-up and trajectory rFFT inside the tile kernel's launch (development A/B)")
     ap.add_argument("--variant", default=None, help="pin a fused-kernel variant (m12, w16s, w16, w8, wpf): development A/B")
     ap.add_argument("--gather", default="mfcc", choices=["mfcc", "full"],
                     help="N > 1: 'mfcc' gathers the MFCC slab and the root computes the modulation spectrum of the "
@@ -276,8 +276,8 @@ def main():
             plan.force_generic(True)
         if a.variant:
             plan.set_variant(a.variant)
-        if a.no_fuse_tail:
-            plan.set_fuse_tail(False)
+        if a.fuse_tail:
+            plan.set_fuse_tail(True)
         audio = synth_batch(torch, dev, b * c, n, cfg.sr, seed0=1000 * rank)
         if c > 1:                      # [B, ch, n]: the rows the kernels see are the channels, stride n
             audio = audio.view(b, c, n)
@@ -314,7 +314,7 @@ def main():
             slab = pg.acquire() if pg else slab1
             mfcc_out, mod_out = lay.views(slab)
             if with_mod and not mod_on_root:
-                plan.mfcc_modspec(rows, out=mfcc_out, out_mod=mod_out)    # one launch where the plan can (fused tail)
+                plan.mfcc_modspec(rows, out=mfcc_out, out_mod=mod_out)    # one launch with --fuse-tail where the plan can
             else:
                 plan.mfcc(rows, out=mfcc_out)
             if pg:
@@ -367,8 +367,10 @@ def main():
         fused = plan.fused_dct
         per_stage = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in stage.items()}
         res["kernels_ms"] = {k: round(v["avg_ms"], 4) for k, v in per_stage.items()}
-        key = {"radix16-w16s": "logmel512s", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(plan.kernel_path)
+        key = {"radix16-w16s": "logmel512s_kernel<1", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(plan.kernel_path)
         ftail = bool(with_mod and not mod_on_root and plan.fused_tail(R, n))
+        if ftail:
+            key = "logmel512s_kernel<2"         # the clip-mode instantiation
         res["config"]["launches_per_step"] = 1 if ftail else (len(per_stage) if per_stage else None)
         res["config"]["fused_tail"] = ftail
         rl = roofline_of(cfg, R, T, n_mod, with_mod, per_stage, fused, key, fused_tail=ftail)
@@ -430,7 +432,7 @@ def main():
                     k = max(5, a.steps // 2)
                     dt2, st2 = time_steps(torch, p2, lambda: p2.mfcc(rows, out=out2), k, 2, ["logmel"])
                     ps = {kk: {"avg_ms": v[0] / v[1], "launches": v[1]} for kk, v in st2.items()}
-                    key2 = {"radix16-w16s": "logmel512s", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(p2.kernel_path)
+                    key2 = {"radix16-w16s": "logmel512s_kernel<1", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(p2.kernel_path)
                     res[name] = {"workload": workload_label(name, WORKLOADS[name][1], T2, c2, 0),
                                  "metric": "MFCC frames/sec", "value": R2 * T2 * k / dt2, "unit": "frames/s",
                                  "ms_per_step": 1e3 * dt2 / k, "steps": k, "kernel_path": p2.kernel_path,

@@ -332,7 +332,7 @@ struct mm_plan {
   size_t dctfm_lds;
   int variant;                     // mm_plan_set_variant: 0 = automatic
   int no_fuse;                     // mm_plan_set_fuse_dct(0): always run the separate clamp + DCT kernel
-  int no_fuse_tail;                // mm_plan_set_fuse_tail(0): mm_mfcc_modspec_f32 always runs its separate launches
+  int no_fuse_tail;                // mm_plan_set_fuse_tail(1) clears it: mm_mfcc_modspec_f32 may run as one launch (opt-in)
   unsigned s16f_red_off;           // clip mode: LDS offset of the per-wave clip max / min slots
 
   float* d_window_e;                       // n_fft < 512 embedded in the 512-point kernels: window centred in 512
@@ -594,7 +594,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0;
-  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 0; p->s16f_red_off = 0; p->d_dctfm_a = nullptr;
+  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 1; p->s16f_red_off = 0; p->d_dctfm_a = nullptr;
   p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {

@@ -23,5 +23,6 @@ for rep in range(3):
     a = t(lambda: plan.mfcc_modspec(audio, out=m, out_mod=s))
     plan.set_fuse_tail(True)
     b = t(lambda: plan.mfcc_modspec(audio, out=m, out_mod=s))
+    fused = plan.fused_tail(B, n)
     c = t(lambda: plan.mfcc(audio, out=m))
-    print(f"separate {a:.4f} ms   fused tail {b:.4f} ms   (mfcc alone {c:.4f} ms)  fused={plan.fused_tail(B, n)}", flush=True)
+    print(f"separate {a:.4f} ms   fused tail {b:.4f} ms   (mfcc alone {c:.4f} ms)  fused={fused}", flush=True)
