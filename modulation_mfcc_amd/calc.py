@@ -20,7 +20,10 @@ def _is_device_tensor(x):
     return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
 
 
-_HILBERT_PLANS = {}
+import collections
+
+_HILBERT_PLANS = collections.OrderedDict()     # (n, dtype, device) -> _HilbertPlan, least recently used first
+HILBERT_MAX_PLANS = 8           # every clip length has its own tables (a Bluestein length: ~13 n complex values)
 HILBERT_WS_BYTES = 4 << 30      # workspace bound of one mm_hilbert_envelope call: batches are cut to fit
 
 
@@ -71,7 +74,13 @@ def hilbert_envelope_batch(x):
         return out[0] if squeeze else out
     code = 0 if x.dtype == torch.float32 else 1
     key = (n, code, str(x.device))
-    if key not in _HILBERT_PLANS:
+    if key in _HILBERT_PLANS:
+        _HILBERT_PLANS.move_to_end(key)
+    else:
+        while len(_HILBERT_PLANS) >= HILBERT_MAX_PLANS:      # files of many different lengths: bounded table memory
+            _, old = _HILBERT_PLANS.popitem(last=False)
+            torch.cuda.synchronize(x.device)                  # nothing in flight may still read the tables
+            del old
         _HILBERT_PLANS[key] = _HilbertPlan(n, code, x.device)
     plan = _HILBERT_PLANS[key]
     lib = _lib.load()

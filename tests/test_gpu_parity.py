@@ -872,6 +872,7 @@ def test_hilbert_envelope_on_device(dt, gpu):
         assert got.is_cuda and got.shape == want.shape and got.cpu().numpy().dtype == dt
         err = np.abs(got.cpu().numpy() - want).max()
         assert err <= tol * max(want.max(), 1e-30), (n, err, want.max())
+    assert len(calc._HILBERT_PLANS) <= calc.HILBERT_MAX_PLANS          # table memory stays bounded over many lengths
     # a strided view (every other row of a bigger batch) and a single clip
     big = _dev(rng.standard_normal((6, 3001)).astype(dt), gpu)
     got = calc.hilbert_envelope_batch(big[::2]).cpu().numpy()
