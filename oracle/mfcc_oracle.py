@@ -226,6 +226,28 @@ def mfcc(y, cfg, fft_dtype=np.float64):
     return mfcc_from_logmel(S, cfg.n_mfcc)
 
 
+def mfcc_f64(y, cfg):
+    """librosa.feature.mfcc for a FLOAT64 signal: [n_mfcc, T] float64.
+
+    librosa keeps the precision of its input (util.dtype_r2c: a float64 signal gives a complex128 STFT and
+    float64 power, mel, dB and DCT arrays; the mel basis keeps its float32 VALUES).  librosa.load returns float32,
+    so the reference's own path never takes this branch -- an ndarray caller can.  The build computes every
+    input in float32 (stated in modulation_mfcc_amd/mfcc.py); the tests bound the difference with this function."""
+    y = np.asarray(y, dtype=np.float64)
+    if cfg.preemph:
+        y = np.concatenate([y[:1], y[1:] - cfg.preemph * y[:-1]])
+    frames = frame_signal(y, cfg.n_fft, cfg.hop_length, 0.0)
+    win = hann_window_padded(cfg.win_length, cfg.n_fft)
+    P = np.abs(np.fft.rfft(frames * win, axis=-1)) ** 2
+    W = mel_filterbank(cfg.sr, cfg.n_fft, cfg.n_mels, cfg.fmin, cfg.fmax).astype(np.float64)
+    S = np.einsum("tf,mf->tm", P, W, optimize=True)
+    log_spec = 10.0 * np.log10(np.maximum(cfg.amin, S)) - 10.0 * np.log10(max(cfg.amin, 1.0))
+    if cfg.top_db is not None:
+        log_spec = np.maximum(log_spec, log_spec.max() - cfg.top_db)
+    M = scipy.fftpack.dct(log_spec.T, axis=-2, type=2, norm="ortho")
+    return np.ascontiguousarray(M[:cfg.n_mfcc, :])
+
+
 def next_pow2(n):
     p = 1
     while p < n:

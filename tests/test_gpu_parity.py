@@ -644,6 +644,19 @@ def test_drop_in_get_MFCCS_change(gpu):
     np.testing.assert_allclose(tot2, tot, rtol=1e-12)
 
 
+@pytest.mark.parametrize("name", ["c1_am", "c1_quiet_tail", "odd_22k", "c4_am"])
+def test_float64_input_is_computed_in_float32(name, gpu):
+    """An ndarray caller may hand the reference a float64 signal, which librosa then transforms in double precision
+    (complex128 STFT; oracle mfcc_f64).  The build computes every input in float32 (librosa.load's dtype): the
+    result stays inside the north-star tolerance of that double-precision path."""
+    from modulation_mfcc_amd.mfcc import mfcc_array
+    from modulation_mfcc_amd import MfccConfig
+    kw, y, _ = load_golden(name)
+    got = mfcc_array(y.astype(np.float64), MfccConfig(**kw))
+    assert got.dtype == np.float32
+    mfcc_close(got, O.mfcc_f64(y.astype(np.float64), O.OracleConfig(**kw)), f"{name}: float64 signal")
+
+
 def test_error_behaviour(gpu):
     import torch
     kw, y, _ = load_golden("c1_am")

@@ -5,7 +5,7 @@ import scipy.fftpack
 import scipy.signal
 
 import mfcc_oracle as O
-from conftest import GOLDEN_NAMES, load_golden
+from conftest import GOLDEN_NAMES, load_golden, mfcc_close
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
@@ -100,3 +100,16 @@ def test_oracle_matches_the_independent_implementation():
         got = O.mfcc(y, O.OracleConfig(**kw))
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), name
+
+
+def test_float64_branch_of_the_oracle():
+    """librosa keeps a float64 signal in double precision (complex128 STFT); librosa.load never produces one, an
+    ndarray caller can.  mfcc_f64 restates that branch; it agrees with the float32 branch to float32 round-off, which
+    is what lets the build compute every input in float32 (GPU test test_float64_input_is_computed_in_float32)."""
+    kw, y, exp = load_golden("c1_am")
+    cfg = O.OracleConfig(**kw)
+    m64 = O.mfcc_f64(y.astype(np.float64), cfg)
+    assert m64.dtype == np.float64 and m64.shape == exp["mfcc"].shape
+    mfcc_close(exp["mfcc"], m64, "float32 branch vs float64 branch")
+    kw2, y2, exp2 = load_golden("c1_quiet_tail")
+    mfcc_close(exp2["mfcc"], O.mfcc_f64(y2.astype(np.float64), O.OracleConfig(**kw2)), "clamp case")
