@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c4 / rFFT-stage passes (profiling runs)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernels")
-    ap.add_argument("--fuse-tail", action="store_true", help="opt-in: clamp fix-up and trajectory rFFT inside the tile kernel's launch (development A/B)")
+    ap.add_argument("--no-fuse-tail", action="store_true", help="separate launches for the clamp fix-up and the trajectory rFFT (development A/B)")
     ap.add_argument("--variant", default=None, help="pin a fused-kernel variant (m12, w16s, w16, w8, wpf): development A/B")
     ap.add_argument("--gather", default="mfcc", choices=["mfcc", "full"],
                     help="N > 1: 'mfcc' gathers the MFCC slab and the root computes the modulation spectrum of the "
@@ -276,8 +276,8 @@ def main():
             plan.force_generic(True)
         if a.variant:
             plan.set_variant(a.variant)
-        if a.fuse_tail:
-            plan.set_fuse_tail(True)
+        if a.no_fuse_tail:
+            plan.set_fuse_tail(False)
         audio = synth_batch(torch, dev, b * c, n, cfg.sr, seed0=1000 * rank)
         if c > 1:                      # [B, ch, n]: the rows the kernels see are the channels, stride n
             audio = audio.view(b, c, n)
@@ -314,7 +314,7 @@ def main():
             slab = pg.acquire() if pg else slab1
             mfcc_out, mod_out = lay.views(slab)
             if with_mod and not mod_on_root:
-                plan.mfcc_modspec(rows, out=mfcc_out, out_mod=mod_out)    # one launch with --fuse-tail where the plan can
+                plan.mfcc_modspec(rows, out=mfcc_out, out_mod=mod_out)    # one launch where the plan can (fused tail)
             else:
                 plan.mfcc(rows, out=mfcc_out)
             if pg:
@@ -337,6 +337,76 @@ def main():
             assert torch.equal(pg.received[last][0], pg.slabs[last]), "gathered slab differs"
         return dt, stage, mod_on_root
 
+    def run_extras():
+        """The bench's other sections -- stage-isolated rFFT, device copy, BASELINE configs[1] and configs[3] -- run
+        BEFORE the headline region: they are ~100 ms of GPU work, after which the clocks are at their steady state
+        (with the driver's 5 warmup steps = 2.5 ms alone, the 10 ms timed region falls into the clock ramp and reads
+        15 % slow: 0.50 vs 0.43 ms per step on the same box)."""
+        ex = {}
+        # ---- stage-isolated batched rFFT (frames in -> complex bins out), same process ---------
+        nrows = R * T
+        frames_buf = torch.randn((nrows, cfg.n_fft), device=dev, dtype=torch.float32)
+        spec = torch.empty((nrows, cfg.n_bins), dtype=torch.complex64, device=dev)
+        for _ in range(3):
+            plan.rfft(frames_buf, cfg.n_fft, out=spec)
+        torch.cuda.synchronize()
+        plan.timing_enable(True)
+        for _ in range(10):
+            plan.rfft(frames_buf, cfg.n_fft, out=spec)
+        plan.timing_enable(False)
+        ms, cnt = plan.timing_read()["rfft"]
+        bpf = 4 * cfg.n_fft + 8 * cfg.n_bins
+        ach = nrows * bpf / (ms / cnt * 1e-3) / 1e9
+        ex["rfft_stage"] = {"kernel": "batched rFFT-%d, %d rows" % (cfg.n_fft, nrows), "bound": "hbm",
+                             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": bpf,
+                             "frames_per_s": nrows / (ms / cnt * 1e-3), "avg_launch_ms": ms / cnt}
+        # practical HBM ceiling of this device: float4 grid-stride copy kernel of the library (bytes
+        # read + written), on the same stream, timed with events
+        src_c = frames_buf.view(-1)[: (1 << 28)]              # 1 GiB
+        dst_c = torch.empty_like(src_c)
+        lib = _lib.load()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for _ in range(2):
+            _lib.check(lib.mm_devcopy_f32(src_c.data_ptr(), dst_c.data_ptr(), src_c.numel(), st), "mm_devcopy_f32")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            lib.mm_devcopy_f32(src_c.data_ptr(), dst_c.data_ptr(), src_c.numel(), st)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src_c.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        ex["rfft_stage"]["device_copy_GBs"] = copy_gbs
+        ex["rfft_stage"]["frac_of_device_copy"] = ach / copy_gbs
+        ex["_copy_gbs"] = copy_gbs
+        del frames_buf, spec, src_c, dst_c
+
+        # ---- the other single-GPU configurations, same process (N = 1 only) --------------------
+        if world == 1:
+            for name in ("c2", "c4"):
+                if name == a.workload:
+                    continue
+                c2, p2, audio2, n2, T2 = make(name)
+                rows2 = audio2.reshape(-1, n2)
+                R2 = rows2.shape[0]
+                out2 = torch.empty((R2, c2.n_mfcc, T2), dtype=torch.float32, device=dev)
+                p2.workspace(R2, n2)
+                k = max(5, a.steps // 2)
+                dt2, st2 = time_steps(torch, p2, lambda: p2.mfcc(rows2, out=out2), k, 2, ["logmel"])
+                ps = {kk: {"avg_ms": v[0] / v[1], "launches": v[1]} for kk, v in st2.items()}
+                key2 = {"radix16-w16s": "logmel512s_kernel<1", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(p2.kernel_path)
+                ex[name] = {"workload": workload_label(name, WORKLOADS[name][1], T2, c2, 0),
+                             "metric": "MFCC frames/sec", "value": R2 * T2 * k / dt2, "unit": "frames/s",
+                             "ms_per_step": 1e3 * dt2 / k, "steps": k, "kernel_path": p2.kernel_path,
+                             "kernels_ms": {kk: round(v["avg_ms"], 4) for kk, v in ps.items()},
+                             "roofline": roofline_of(c2, R2, T2, 0, False, ps, p2.fused_dct, key2)}
+                del out2, audio2, rows2
+                torch.cuda.empty_cache()
+
+
+        return ex
+
+    extras = run_extras() if not a.no_extra else {}
     dt, stage, mod_on_root = run_variant(a.gather, a.steps, a.warmup)
     frames_total = world * R * T * a.steps
     res = {
@@ -377,68 +447,12 @@ def main():
         if rl:
             res["roofline"] = rl
 
-        if not a.no_extra:
-            # ---- stage-isolated batched rFFT (frames in -> complex bins out), same process ---------
-            nrows = R * T
-            frames_buf = torch.randn((nrows, cfg.n_fft), device=dev, dtype=torch.float32)
-            spec = torch.empty((nrows, cfg.n_bins), dtype=torch.complex64, device=dev)
-            for _ in range(3):
-                plan.rfft(frames_buf, cfg.n_fft, out=spec)
-            torch.cuda.synchronize()
-            plan.timing_enable(True)
-            for _ in range(10):
-                plan.rfft(frames_buf, cfg.n_fft, out=spec)
-            plan.timing_enable(False)
-            ms, cnt = plan.timing_read()["rfft"]
-            bpf = 4 * cfg.n_fft + 8 * cfg.n_bins
-            ach = nrows * bpf / (ms / cnt * 1e-3) / 1e9
-            res["rfft_stage"] = {"kernel": "batched rFFT-%d, %d rows" % (cfg.n_fft, nrows), "bound": "hbm",
-                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": bpf,
-                                 "frames_per_s": nrows / (ms / cnt * 1e-3), "avg_launch_ms": ms / cnt}
-            # practical HBM ceiling of this device: float4 grid-stride copy kernel of the library (bytes
-            # read + written), on the same stream, timed with events
-            src_c = frames_buf.view(-1)[: (1 << 28)]              # 1 GiB
-            dst_c = torch.empty_like(src_c)
-            lib = _lib.load()
-            st = torch.cuda.current_stream(dev).cuda_stream
-            for _ in range(2):
-                _lib.check(lib.mm_devcopy_f32(src_c.data_ptr(), dst_c.data_ptr(), src_c.numel(), st), "mm_devcopy_f32")
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                lib.mm_devcopy_f32(src_c.data_ptr(), dst_c.data_ptr(), src_c.numel(), st)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbs = 5 * 2 * src_c.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            res["rfft_stage"]["device_copy_GBs"] = copy_gbs
-            res["rfft_stage"]["frac_of_device_copy"] = ach / copy_gbs
-            if "roofline" in res:
-                res["roofline"]["device_copy_GBs"] = copy_gbs
-            del frames_buf, spec, src_c, dst_c
-
-            # ---- the other single-GPU configurations, same process (N = 1 only) --------------------
-            if world == 1:
-                for name in ("c2", "c4"):
-                    if name == a.workload:
-                        continue
-                    del audio, rows
-                    torch.cuda.empty_cache()
-                    c2, p2, audio, n2, T2 = make(name)
-                    rows = audio.reshape(-1, n2)
-                    R2 = rows.shape[0]
-                    out2 = torch.empty((R2, c2.n_mfcc, T2), dtype=torch.float32, device=dev)
-                    p2.workspace(R2, n2)
-                    k = max(5, a.steps // 2)
-                    dt2, st2 = time_steps(torch, p2, lambda: p2.mfcc(rows, out=out2), k, 2, ["logmel"])
-                    ps = {kk: {"avg_ms": v[0] / v[1], "launches": v[1]} for kk, v in st2.items()}
-                    key2 = {"radix16-w16s": "logmel512s_kernel<1", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(p2.kernel_path)
-                    res[name] = {"workload": workload_label(name, WORKLOADS[name][1], T2, c2, 0),
-                                 "metric": "MFCC frames/sec", "value": R2 * T2 * k / dt2, "unit": "frames/s",
-                                 "ms_per_step": 1e3 * dt2 / k, "steps": k, "kernel_path": p2.kernel_path,
-                                 "kernels_ms": {kk: round(v["avg_ms"], 4) for kk, v in ps.items()},
-                                 "roofline": roofline_of(c2, R2, T2, 0, False, ps, p2.fused_dct, key2)}
-                    del out2
+        res["config"]["sections_before_headline"] = sorted(k_ for k_ in extras if not k_.startswith("_"))
+        for k_, v_ in extras.items():
+            if k_ != "_copy_gbs":
+                res[k_] = v_
+        if "_copy_gbs" in extras and "roofline" in res:
+            res["roofline"]["device_copy_GBs"] = extras["_copy_gbs"]
 
         if cpu is not None:
             res["cpu_baseline"] = cpu

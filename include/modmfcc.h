@@ -138,10 +138,11 @@ int mm_plan_fused_dct(const mm_plan* plan);
  * previous setting.  Default on. */
 int mm_plan_set_fuse_dct(mm_plan* plan, int on);
 /* mm_mfcc_modspec_f32 in ONE launch (whole clips per workgroup: the clip maximum / minimum never leave it, the
- * clamp fix-up and the trajectory rFFT run inside the tile kernel)?  1 when the n_fft 512 staged-sample kernel
- * with its fused DCT takes the call, the trajectory length is 512 or 1024 and `batch` clips spread over the
- * compute units within 4 %; 0 = the separate launches.  OPT-IN: mm_plan_set_fuse_tail(plan, 1) enables it
- * (returns the previous setting; default off -- measured at parity with the separate launches). */
+ * clamp fix-up and the trajectory rFFT of the workgroup's clips run at the end of the tile kernel)?  1 when the
+ * n_fft 512 staged-sample kernel with its fused DCT takes the call, the trajectory length is 512 or 1024 and
+ * `batch` clips spread over the compute units within 4 % (at most 8 per workgroup); 0 = the separate launches.
+ * mm_plan_set_fuse_tail(plan, 0) pins the separate launches (A/B measurements, cross-checks; returns the previous
+ * setting; default on). */
 int mm_plan_fused_tail(const mm_plan* plan, int64_t batch, int64_t n_samples);
 int mm_plan_set_fuse_tail(mm_plan* plan, int on);
 /* force the generic kernels (debug / cross-check); returns previous value */

@@ -20,7 +20,7 @@ def modspec_batch(mfcc, cfg: MfccConfig, out=None):
 
 def mfcc_modspec_batch(audio, cfg: MfccConfig, mfcc_out=None, mod_out=None):
     """The whole hot path: MFCC and its modulation spectrum."""
-    return get_plan(cfg).mfcc_modspec(audio, out=mfcc_out, out_mod=mod_out)     # one launch if the plan was told to fuse the tail
+    return get_plan(cfg).mfcc_modspec(audio, out=mfcc_out, out_mod=mod_out)     # one launch where the plan can
 
 
 def rfft_batch(rows, n: int, cfg: MfccConfig = None, out=None):

@@ -332,7 +332,7 @@ struct mm_plan {
   size_t dctfm_lds;
   int variant;                     // mm_plan_set_variant: 0 = automatic
   int no_fuse;                     // mm_plan_set_fuse_dct(0): always run the separate clamp + DCT kernel
-  int no_fuse_tail;                // mm_plan_set_fuse_tail(1) clears it: mm_mfcc_modspec_f32 may run as one launch (opt-in)
+  int no_fuse_tail;                // mm_plan_set_fuse_tail(0): mm_mfcc_modspec_f32 always runs its separate launches
   unsigned s16f_red_off;           // clip mode: LDS offset of the per-wave clip max / min slots
 
   float* d_window_e;                       // n_fft < 512 embedded in the 512-point kernels: window centred in 512
@@ -594,7 +594,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0;
-  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 1; p->s16f_red_off = 0; p->d_dctfm_a = nullptr;
+  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 0; p->s16f_red_off = 0; p->d_dctfm_a = nullptr;
   p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
@@ -1037,10 +1037,11 @@ struct StftOut {
 // others sets the launch time, so the uneven case stays on the tile-granular split + separate launches.
 static bool s16_clip_mode_ok(const mm_plan* p, int64_t batch, int n_mod) {
   if (p->no_fuse_tail || !(n_mod == 512 || n_mod == 1024)) return false;
-  if (p->s16f_lds_bytes + MM_S16_FIN_TAB_BYTES > MM_LM_LDS_MAX) return false;     // no room for the rFFT twiddles
   const int64_t g = p->num_cus;
   if (batch < g) return false;
   const int64_t per = (batch + g - 1) / g;
+  if (per > MM_S16_CPW_MAX) return false;                                          // extreme slots [per][16] in LDS
+  if ((size_t)p->s16f_red_off + (size_t)per * 128 > MM_LM_LDS_MAX) return false;
   return per * g * 100 <= batch * 104;          // at most 4 % of idle workgroup time
 }
 
@@ -1146,7 +1147,8 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
             o.fused_tail = true;
             q.out_mod = (float2*)o.mod; q.n_mod = o.n_mod; q.dct_t = p->d_dct_t; q.dct_kp = p->kp; q.top_db = p->cfg.top_db;
             grid = batch < p->num_cus ? batch : p->num_cus;
-            lds += MM_S16_FIN_TAB_BYTES;
+            lds = std::max((size_t)p->s16f_red_off + (size_t)((batch + grid - 1) / grid) * 128,
+                           (size_t)MM_S16_FIN_TAB_OFF + MM_S16_FIN_TAB_BYTES);
           }
         }
         launch_s16(mode, p->s16_nr, pre, odd, unal, dim3((unsigned)grid), lds, st, q);

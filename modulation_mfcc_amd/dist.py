@@ -184,7 +184,7 @@ def mfcc_modspec_sharded(audio_all_or_local, cfg: MfccConfig, *, with_modspec=Tr
             from .plan import get_plan
             plan = get_plan(cfg)
             m, ms = lay.views(slab)
-            if send_mod:     # one launch if the plan was told to fuse the tail
+            if send_mod:     # one launch where the plan can (fused tail)
                 plan.mfcc_modspec(local, out=m[:local.shape[0]], out_mod=ms[:local.shape[0]])
             else:
                 plan.mfcc(local, out=m[:local.shape[0]])

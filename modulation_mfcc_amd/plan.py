@@ -241,8 +241,8 @@ class MfccPlan:
         return bool(self._lib.mm_plan_fused_tail(self._h, int(batch), int(n_samples)))
 
     def set_fuse_tail(self, on=True):
-        """Let mfcc_modspec() run as one launch where the plan can (opt-in; default off: measured at parity with the
-        separate launches); returns the previous setting."""
+        """on=False pins the separate launches for mfcc_modspec() (default: one launch where the plan can); returns
+        the previous setting."""
         return bool(self._lib.mm_plan_set_fuse_tail(self._h, 1 if on else 0))
 
     def force_generic(self, on=True):
@@ -269,7 +269,7 @@ class MfccPlan:
     def mfcc_modspec(self, audio, out=None, out_mod=None):
         """[B, n] float32 device tensor -> (MFCC [B, n_mfcc, T] float32, modulation spectrum complex64
         [B, n_mfcc, n_mod/2+1]): mfcc() followed by modspec() (MFCC bit for bit, spectrum to float32 round-off), in
-        one launch after set_fuse_tail(True) where the plan can (fused_tail())."""
+        one launch where the plan can (fused_tail())."""
         torch = _torch()
         audio = self._check_audio(audio)
         B, n = audio.shape

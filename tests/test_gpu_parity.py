@@ -554,7 +554,7 @@ def test_full_size_properties(gpu):
     (dict(n_mfcc=20, n_mels=64), 160000, (256,)),             # no fused DCT for this shape -> separate launches
 ])
 def test_fused_tail_matches_separate_launches(extra, n, batches, gpu):
-    """mm_mfcc_modspec_f32 with the fused tail switched on (opt-in): where the plan runs it as ONE launch (whole clips per workgroup, clip extremes kept in
+    """mm_mfcc_modspec_f32: where the plan runs it as ONE launch (whole clips per workgroup, clip extremes kept in
     the workgroup, clamp fix-up and trajectory rFFT inside the tile kernel) the results equal the separate
     launches' -- MFCC bit for bit, including clips that clamp; modulation spectrum to float32 round-off -- spot
     clips against the oracle; the uneven batch takes the separate launches and says so."""
@@ -569,12 +569,12 @@ def test_fused_tail_matches_separate_launches(extra, n, batches, gpu):
         audio[1::7] = 0.0
         audio[1::7, 1000] = 1.0                                              # an impulse in silence
         even = B % 256 == 0
-        assert not plan.fused_tail(B, n)                                     # opt-in
-        m0, s0 = plan.mfcc_modspec(audio)
-        prev = plan.set_fuse_tail(True)
+        assert plan.fused_tail(B, n) == (even and plan.kernel_path == "radix16-w16s" and plan.fused_dct)
+        m1, s1 = plan.mfcc_modspec(audio)
+        prev = plan.set_fuse_tail(False)
         try:
-            assert plan.fused_tail(B, n) == (even and plan.kernel_path == "radix16-w16s" and plan.fused_dct)
-            m1, s1 = plan.mfcc_modspec(audio)
+            assert not plan.fused_tail(B, n)
+            m0, s0 = plan.mfcc_modspec(audio)
         finally:
             plan.set_fuse_tail(prev)
         m2 = plan.mfcc(audio)

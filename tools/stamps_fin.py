@@ -6,7 +6,6 @@ sys.path.insert(0, '.')
 import numpy as np, torch
 from modulation_mfcc_amd import MfccConfig, MfccPlan, _lib
 plan = MfccPlan(MfccConfig(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100., fmax=8000.))
-plan.set_fuse_tail(True)
 x = torch.randn((1024, 160000), device='cuda') * 0.1
 n = 3
 for _ in range(n): plan.mfcc_modspec(x)
