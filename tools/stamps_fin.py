@@ -1,5 +1,5 @@
-"""dev helper: like tools/stamps.py for the clip-mode finalisation (s16_finalize): build with -DMM_STAMP into
-../libmodmfcc_stamp.so, MODMFCC_LIB=that; prints cycles per call (workgroup 0, 4 calls per launch), per wave:
+"""dev helper: like tools/stamps.py for the clip-mode finalisation (s16_finalize_all): build with -DMM_STAMP into
+../libmodmfcc_stamp.so, MODMFCC_LIB=that; prints cycles per launch (workgroup 0, all of a wave's row pairs), per wave:
 row loads arrived | DFT-16 #1 + twiddles + exchange | DFT-16 #2 (+ radix-2) | split + stores issued  (waves 0-6)"""
 import sys, ctypes, os
 sys.path.insert(0, '.')
@@ -13,6 +13,6 @@ torch.cuda.synchronize()
 lib = _lib.load()
 out = (ctypes.c_uint * 128)()
 assert lib.mm_debug_fin_stamps(out) == 0
-a = np.array(out[:]).reshape(16, 8)[:, :4] / (4.0 * n)
+a = np.array(out[:]).reshape(16, 8)[:, :4] / float(n)
 np.set_printoptions(linewidth=200)
 print((a).round(0).astype(int))
