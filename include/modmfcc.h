@@ -140,7 +140,7 @@ int mm_plan_set_fuse_dct(mm_plan* plan, int on);
 /* mm_mfcc_modspec_f32 in ONE launch (whole clips per workgroup: the clip maximum / minimum never leave it, the
  * clamp fix-up and the trajectory rFFT of the workgroup's clips run at the end of the tile kernel)?  1 when the
  * n_fft 512 staged-sample kernel with its fused DCT takes the call, the trajectory length is 512 or 1024 and
- * `batch` clips spread over the compute units within 4 % (at most 8 per workgroup); 0 = the separate launches.
+ * `batch` clips spread over the compute units within 4 % (at most 32 per workgroup); 0 = the separate launches.
  * mm_plan_set_fuse_tail(plan, 0) pins the separate launches (A/B measurements, cross-checks; returns the previous
  * setting; default on). */
 int mm_plan_fused_tail(const mm_plan* plan, int64_t batch, int64_t n_samples);

@@ -547,7 +547,7 @@ def test_full_size_properties(gpu):
 
 @pytest.mark.parametrize("extra,n,batches", [
     (dict(), 160000, (256, 512, 300)),                        # T 1001 -> n_mod 1024; 300 clips: uneven -> separate launches
-    (dict(), 48000, (256, 1024)),                             # T 301 -> n_mod 512
+    (dict(), 48000, (256, 1024, 2560)),                       # T 301 -> n_mod 512; ten clips per workgroup
     (dict(top_db=-1.0), 160000, (256,)),                      # no clamp
     (dict(preemph=0.97, hop_length=161), 48003, (256,)),      # odd hop, unaligned length, pre-emphasis
     (dict(n_mfcc=16), 160000, (256,)),                        # more rows than one pass of the rFFT waves takes
