@@ -870,14 +870,14 @@ def test_hilbert_envelope_on_device(dt, gpu):
     """Row N3: |scipy.signal.hilbert(x)| (script/calc.py:286) through mm_hilbert_envelope -- the library's own
     Stockham FFT at the clip's own length when that is 2^a 3^b 5^c 7^d, Bluestein chirp-z transforms over a
     power-of-two FFT otherwise -- against scipy in float64: lengths 1 .. 480 000 (every pass radix 2 .. 49 alone,
-    first and later; primes; products), batches, a strided batch, a batch cut into workspace-bounded calls."""
+    first and later, the fused radix-256 / radix-625 passes first, later and behind small radices; primes; products), batches, a strided batch, a batch cut into workspace-bounded calls."""
     import scipy.signal
     from modulation_mfcc_amd import calc
     rng = np.random.default_rng(8)
     tol = 2e-5 if dt == np.float32 else 1e-11
     for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 15, 16, 17, 21, 22, 25, 27, 31, 32, 35, 45, 49, 63, 64, 75, 100, 105,
               121, 125, 127, 128, 147, 225, 245, 256, 257, 343, 512, 625, 1000, 1024, 2048, 2401, 4000, 4001, 4096,
-              8191, 8192, 12345, 16807, 44100, 65536, 99991, 117649, 160000, 441000, 480000):
+              768, 1250, 5625, 6250, 8191, 8192, 12345, 16807, 44100, 65536, 99991, 117649, 160000, 390625, 441000, 480000):
         rows = 3 if n > 20000 else 5
         x = (rng.standard_normal((rows, n)) * np.linspace(0.2, 1.0, n)[None, :]).astype(dt)
         want = np.abs(scipy.signal.hilbert(x.astype(np.float64), axis=1))
