@@ -131,11 +131,15 @@ def _device_taps(L, M, dev):
     if key not in _TAPS:
         h, half = design_taps(L, M)
         tpp = -(-len(h) // L)
-        hp = np.zeros((L, tpp), dtype=np.float32)
+        hp = np.zeros((L, tpp), dtype=np.float32)          # polyphase order: hp[p][j] = h[p + j L]
         for p in range(L):
             col = h[p::L]
             hp[p, :len(col)] = col
-        _TAPS[key] = (torch.from_numpy(hp).to(dev), tpp, half)
+        # the kernel wants OUTPUT-phase order [tpp][L]: output index t of a period uses phase (t M + half) mod L,
+        # so adjacent outputs (= adjacent threads) read adjacent taps
+        ph = (np.arange(L, dtype=np.int64) * M + half) % L
+        hq = np.ascontiguousarray(hp[ph, :].T)
+        _TAPS[key] = (torch.from_numpy(hq).to(dev), tpp, half)
     return _TAPS[key]
 
 
@@ -161,8 +165,10 @@ def resample_batch(x, sr_in: float, sr_out: float):
     out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        _lib.check(lib.mm_resample_f32(x2.data_ptr(), rows, n, x2.stride(0), taps.data_ptr(), L, M, tpp, half,
-                                       out.data_ptr(), n_out, _stream(torch, x.device)), "mm_resample_f32")
+        for r0 in range(0, rows, 65535):         # the kernel's grid takes the rows on its y axis
+            r = min(65535, rows - r0)
+            _lib.check(lib.mm_resample_f32(x2[r0:].data_ptr(), r, n, x2.stride(0), taps.data_ptr(), L, M, tpp, half,
+                                           out[r0:].data_ptr(), n_out, _stream(torch, x.device)), "mm_resample_f32")
     return out[0] if squeeze else out
 
 

@@ -1654,39 +1654,82 @@ int mm_pcm_decode_f32(const void* d_raw, int32_t fmt, int32_t channels, int64_t 
   return MM_OK;
 }
 
-// Rational-ratio polyphase FIR resampler: y[m] = sum_i x[i] h[m M - i L + c], c = (len(h) - 1) / 2, zero
-// signal outside the clip -- upfirdn with the filter delay removed, n_out = ceil(n L / M) (what
-// scipy.signal.resample_poly and librosa.resample return).  hp = the taps in polyphase order [L][tpp]:
-// hp[p][j] = h[p + j L]; one thread per output sample, float64 accumulation.
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int64_t rows, int64_t n_in,
-                                                       int64_t in_stride, const float* __restrict__ hp, int L, int M,
-                                                       int tpp, int64_t c, int64_t n_out, float* __restrict__ y) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= rows * n_out) return;
-  const int64_t r = idx / n_out, m = idx - r * n_out;
-  const int64_t t = m * M + c;
-  const int64_t ih = t / L;
-  const int ph = (int)(t - ih * L);
+// Rational-ratio polyphase FIR sample-rate conversion: output m = sum_j h[ph + j L] x[ih - j] with t = m M + c,
+// ih = t div L, ph = t mod L, zero signal outside the clip -- upfirdn with the filter delay c removed, n_out =
+// ceil(n L / M) (what scipy.signal.resample_poly and librosa.resample return); float64 accumulation.
+// A thread computes MM_RS_P outputs of ONE phase (m, m + F, m + 2F, ..., F a multiple of L), so a tap is fetched
+// once for all of them, and the taps come in OUTPUT-phase order, hq[j][t] = h[ph_t + j L] with ph_t = (t M + c)
+// mod L for the output index t within a period: adjacent threads = adjacent outputs read adjacent taps
+// (unit-stride), and their input samples lie within a few cache lines of each other.  (The first version -- one
+// thread per output, taps in polyphase order [L][tpp], i.e. a 2 KB stride between lanes -- ran at 0.3 T
+// multiply-adds per second: 66 ms for 256 ten-second clips 44.1 -> 16 kHz.)
+#define MM_RS_P 4
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int64_t n_in, int64_t in_stride,
+                                                       const float* __restrict__ hq, int L, int M, int tpp, int64_t c,
+                                                       int64_t n_out, int64_t F, float* __restrict__ y) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const int64_t r = blockIdx.y;
   const float* xr = x + r * in_stride;
-  const float* h = hp + (int64_t)ph * tpp;
-  double acc = 0.0;
-  for (int j = 0; j < tpp; ++j) {
-    const int64_t i = ih - j;
-    if (i >= 0 && i < n_in) acc = fma((double)h[j], (double)xr[i], acc);
+  const int t = (int)(f % L);
+  const int64_t t0 = f * M + c;                   // F is a multiple of L: output f + i F has the phase of output f
+  const int64_t ih0 = t0 / L, step = (F / L) * M;
+  double acc[MM_RS_P];
+  int64_t ih[MM_RS_P];
+#pragma unroll
+  for (int i = 0; i < MM_RS_P; ++i) { acc[i] = 0.0; ih[i] = ih0 + i * step; }
+  const float* h = hq + t;
+  // taps j for which EVERY one of the thread's outputs reads inside the clip: no checks there
+  int64_t jlo = 0, jhi = tpp;
+#pragma unroll
+  for (int i = 0; i < MM_RS_P; ++i) {
+    const int64_t lo = ih[i] - (n_in - 1), hi = ih[i] + 1;      // valid j: lo <= j < hi
+    jlo = lo > jlo ? lo : jlo;
+    jhi = hi < jhi ? hi : jhi;
   }
-  y[r * n_out + m] = (float)acc;
+  if (jhi < jlo) jhi = jlo;
+  if (jlo > tpp) jlo = jhi = tpp;
+  for (int64_t j = 0; j < jlo; ++j) {
+    const double tap = (double)h[j * L];
+#pragma unroll
+    for (int i = 0; i < MM_RS_P; ++i) {
+      const int64_t idx = ih[i] - j;
+      if (idx >= 0 && idx < n_in) acc[i] = fma(tap, (double)xr[idx], acc[i]);
+    }
+  }
+#pragma unroll 4
+  for (int64_t j = jlo; j < jhi; ++j) {
+    const double tap = (double)h[j * L];
+#pragma unroll
+    for (int i = 0; i < MM_RS_P; ++i) acc[i] = fma(tap, (double)xr[ih[i] - j], acc[i]);
+  }
+  for (int64_t j = jhi; j < tpp; ++j) {
+    const double tap = (double)h[j * L];
+#pragma unroll
+    for (int i = 0; i < MM_RS_P; ++i) {
+      const int64_t idx = ih[i] - j;
+      if (idx >= 0 && idx < n_in) acc[i] = fma(tap, (double)xr[idx], acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MM_RS_P; ++i) {
+    const int64_t m = f + i * F;
+    if (m < n_out) y[r * n_out + m] = (float)acc[i];
+  }
 }
 
 int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_taps, int32_t L, int32_t M,
                     int32_t taps_per_phase, int64_t half_len, float* d_y, int64_t n_out, void* stream) {
   if (!d_x || !d_taps || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || L < 1 || M < 1 || taps_per_phase < 1 ||
-      half_len < 0 || n_out < 1)
+      half_len < 0 || n_out < 1 || rows > 65535)
     return MM_ERR_INVALID_ARG;
   if (n_out != (n_in * L + M - 1) / M) return MM_ERR_INVALID_ARG;
-  const int64_t total = rows * n_out;
-  if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, rows, n_in,
-                     x_stride, d_taps, L, M, taps_per_phase, half_len, n_out, d_y);
+  // threads per row: ceil(n_out / P) rounded up to a multiple of L
+  const int64_t per = (n_out + MM_RS_P - 1) / MM_RS_P;
+  const int64_t F = (per + L - 1) / L * L;
+  if ((F + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, d_x,
+                     n_in, x_stride, d_taps, L, M, taps_per_phase, half_len, n_out, F, d_y);
   HIP_TRY(hipGetLastError());
   return MM_OK;
 }
