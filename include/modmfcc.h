@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 113 /* 0.2.3 */
+#define MM_VERSION 114 /* 0.2.4 */
 
 typedef enum mm_status {
   MM_OK = 0,
@@ -255,8 +255,9 @@ int mm_hilbert_envelope(mm_hilbert* h, const void* d_x, int64_t rows, int64_t x_
  *   [-1, 1) as libsndfile does.
  * mm_resample_f32: rational-ratio (L / M) polyphase FIR sample-rate conversion, zero-phase, n_out =
  *   ceil(n_in * L / M) as librosa.resample returns; d_taps = DEVICE pointer to the low-pass taps (DC gain L) in
- *   OUTPUT-phase order [taps_per_phase][L]: taps[j][t] = h[ph_t + j * L] with ph_t = (t * M + half_len) mod L the
- *   polyphase branch of the t-th output of a period, half_len = (len(h) - 1) / 2; rows <= 65535.  The host
+ *   OUTPUT-phase order, records of four: taps[j / 4][t][j % 4] = h[ph_t + j * L] with ph_t = (t * M + half_len)
+ *   mod L the polyphase branch of the t-th output of a period (taps_per_phase a multiple of 4, zero padded; 16-byte
+ *   aligned), half_len = (len(h) - 1) / 2; rows <= 65535.  The host
  *   designs h (modulation_mfcc_amd/audio_io.py: a Kaiser-windowed sinc of soxr-HQ class: pass band to 0.913 of
  *   the lower Nyquist, > 120 dB stop band); the reference's resampler is soxr_hq, whose coefficients are not
  *   public API, so outputs agree with it to the quality of both filters, not bit for bit. */

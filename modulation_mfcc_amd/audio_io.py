@@ -130,15 +130,15 @@ def _device_taps(L, M, dev):
     key = (L, M, str(dev))
     if key not in _TAPS:
         h, half = design_taps(L, M)
-        tpp = -(-len(h) // L)
+        tpp = -(-(-(-len(h) // L)) // 4) * 4                # taps per output, padded to a multiple of 4 with zeros
         hp = np.zeros((L, tpp), dtype=np.float32)          # polyphase order: hp[p][j] = h[p + j L]
         for p in range(L):
             col = h[p::L]
             hp[p, :len(col)] = col
-        # the kernel wants OUTPUT-phase order [tpp][L]: output index t of a period uses phase (t M + half) mod L,
-        # so adjacent outputs (= adjacent threads) read adjacent taps
+        # the kernel wants OUTPUT-phase order in records of four, [tpp / 4][L][4]: output index t of a period uses
+        # phase (t M + half) mod L, so adjacent outputs (= adjacent threads) read adjacent 16-byte records
         ph = (np.arange(L, dtype=np.int64) * M + half) % L
-        hq = np.ascontiguousarray(hp[ph, :].T)
+        hq = np.ascontiguousarray(hp[ph, :].reshape(L, tpp // 4, 4).transpose(1, 0, 2))
         _TAPS[key] = (torch.from_numpy(hq).to(dev), tpp, half)
     return _TAPS[key]
 

@@ -1658,14 +1658,16 @@ int mm_pcm_decode_f32(const void* d_raw, int32_t fmt, int32_t channels, int64_t 
 // ih = t div L, ph = t mod L, zero signal outside the clip -- upfirdn with the filter delay c removed, n_out =
 // ceil(n L / M) (what scipy.signal.resample_poly and librosa.resample return); float64 accumulation.
 // A thread computes MM_RS_P outputs of ONE phase (m, m + F, m + 2F, ..., F a multiple of L), so a tap is fetched
-// once for all of them, and the taps come in OUTPUT-phase order, hq[j][t] = h[ph_t + j L] with ph_t = (t M + c)
-// mod L for the output index t within a period: adjacent threads = adjacent outputs read adjacent taps
-// (unit-stride), and their input samples lie within a few cache lines of each other.  (The first version -- one
+// once for all of them, and the taps come in OUTPUT-phase order in records of four, hq4[j / 4][t][j % 4] = h[ph_t +
+// j L] with ph_t = (t M + c) mod L for the output index t within a period: adjacent threads = adjacent outputs read
+// adjacent 16-byte records, their input samples lie within a few cache lines of each other and are fetched four at
+// a time (16-byte loads at 4-byte aligned addresses).  (The first version -- one
 // thread per output, taps in polyphase order [L][tpp], i.e. a 2 KB stride between lanes -- ran at 0.3 T
 // multiply-adds per second: 66 ms for 256 ten-second clips 44.1 -> 16 kHz.)
 #define MM_RS_P 4
+struct __attribute__((packed, aligned(4))) MmRsFloat4U { float x, y, z, w; };
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int64_t n_in, int64_t in_stride,
-                                                       const float* __restrict__ hq, int L, int M, int tpp, int64_t c,
+                                                       const float* __restrict__ hq, int L, int M, int tpp4, int64_t c,
                                                        int64_t n_out, int64_t F, float* __restrict__ y) {
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= F) return;
@@ -1678,8 +1680,11 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
   int64_t ih[MM_RS_P];
 #pragma unroll
   for (int i = 0; i < MM_RS_P; ++i) { acc[i] = 0.0; ih[i] = ih0 + i * step; }
-  const float* h = hq + t;
-  // taps j for which EVERY one of the thread's outputs reads inside the clip: no checks there
+  // taps of this output phase, four consecutive j per 16-byte record: record j4 at hq4[j4 * L + t]
+  const float4* h4 = reinterpret_cast<const float4*>(hq) + t;
+  const float* h1 = hq + 4 * (int64_t)t;
+  const int tpp = 4 * tpp4;
+  // taps j for which EVERY one of the thread's outputs reads inside the clip: no checks there, whole records only
   int64_t jlo = 0, jhi = tpp;
 #pragma unroll
   for (int i = 0; i < MM_RS_P; ++i) {
@@ -1687,30 +1692,35 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     jlo = lo > jlo ? lo : jlo;
     jhi = hi < jhi ? hi : jhi;
   }
+  jlo = (jlo + 3) / 4 * 4;
+  jhi = jhi / 4 * 4;
+  if (jlo > tpp) jlo = tpp;
   if (jhi < jlo) jhi = jlo;
-  if (jlo > tpp) jlo = jhi = tpp;
-  for (int64_t j = 0; j < jlo; ++j) {
-    const double tap = (double)h[j * L];
+  auto checked = [&](int64_t ja, int64_t jb) {
+    for (int64_t j = ja; j < jb; ++j) {
+      const double tap = (double)h1[(j >> 2) * 4 * L + (j & 3)];
+#pragma unroll
+      for (int i = 0; i < MM_RS_P; ++i) {
+        const int64_t idx = ih[i] - j;
+        if (idx >= 0 && idx < n_in) acc[i] = fma(tap, (double)xr[idx], acc[i]);
+      }
+    }
+  };
+  checked(0, jlo);
+#pragma unroll 2
+  for (int64_t j = jlo; j < jhi; j += 4) {
+    const float4 tp = h4[(j >> 2) * L];
 #pragma unroll
     for (int i = 0; i < MM_RS_P; ++i) {
-      const int64_t idx = ih[i] - j;
-      if (idx >= 0 && idx < n_in) acc[i] = fma(tap, (double)xr[idx], acc[i]);
+      // x[ih - j - 3 .. ih - j]: one 16-byte load at a 4-byte aligned address
+      const MmRsFloat4U xv = *reinterpret_cast<const MmRsFloat4U*>(xr + (ih[i] - j - 3));
+      acc[i] = fma((double)tp.x, (double)xv.w, acc[i]);
+      acc[i] = fma((double)tp.y, (double)xv.z, acc[i]);
+      acc[i] = fma((double)tp.z, (double)xv.y, acc[i]);
+      acc[i] = fma((double)tp.w, (double)xv.x, acc[i]);
     }
   }
-#pragma unroll 4
-  for (int64_t j = jlo; j < jhi; ++j) {
-    const double tap = (double)h[j * L];
-#pragma unroll
-    for (int i = 0; i < MM_RS_P; ++i) acc[i] = fma(tap, (double)xr[ih[i] - j], acc[i]);
-  }
-  for (int64_t j = jhi; j < tpp; ++j) {
-    const double tap = (double)h[j * L];
-#pragma unroll
-    for (int i = 0; i < MM_RS_P; ++i) {
-      const int64_t idx = ih[i] - j;
-      if (idx >= 0 && idx < n_in) acc[i] = fma(tap, (double)xr[idx], acc[i]);
-    }
-  }
+  checked(jhi, tpp);
 #pragma unroll
   for (int i = 0; i < MM_RS_P; ++i) {
     const int64_t m = f + i * F;
@@ -1720,8 +1730,8 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 
 int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_taps, int32_t L, int32_t M,
                     int32_t taps_per_phase, int64_t half_len, float* d_y, int64_t n_out, void* stream) {
-  if (!d_x || !d_taps || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || L < 1 || M < 1 || taps_per_phase < 1 ||
-      half_len < 0 || n_out < 1 || rows > 65535)
+  if (!d_x || !d_taps || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || L < 1 || M < 1 || taps_per_phase < 4 ||
+      (taps_per_phase & 3) || half_len < 0 || n_out < 1 || rows > 65535 || (((uintptr_t)d_taps) & 15))
     return MM_ERR_INVALID_ARG;
   if (n_out != (n_in * L + M - 1) / M) return MM_ERR_INVALID_ARG;
   // threads per row: ceil(n_out / P) rounded up to a multiple of L
@@ -1729,7 +1739,7 @@ int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stri
   const int64_t F = (per + L - 1) / L * L;
   if ((F + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, d_x,
-                     n_in, x_stride, d_taps, L, M, taps_per_phase, half_len, n_out, F, d_y);
+                     n_in, x_stride, d_taps, L, M, taps_per_phase / 4, half_len, n_out, F, d_y);
   HIP_TRY(hipGetLastError());
   return MM_OK;
 }
