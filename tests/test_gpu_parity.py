@@ -996,6 +996,18 @@ def test_load_and_resample_on_device(tmp_path, gpu):
         want = scipy.signal.resample_poly(xs.astype(np.float64), L, M, axis=1, window=h.astype(np.float32).astype(np.float64) / L)
         assert got.shape == want.shape == (3, -(-20000 * L // M))
         assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    # clips shorter than the filter (every tap range is clipped at both ends), odd lengths, a single row, upsampling
+    for n, sr_in, sr_out in ((1, 44100, 16000), (7, 44100, 16000), (300, 44100, 16000), (301, 48000, 16000), (999, 16000, 44100),
+                             (4097, 22050, 16000), (50001, 44100, 16000)):
+        xr = rng.standard_normal((2, n)).astype(np.float32)
+        L, M = resample_ratio(sr_in, sr_out)
+        h, half = design_taps(L, M)
+        want = scipy.signal.resample_poly(xr.astype(np.float64), L, M, axis=1, window=h.astype(np.float32).astype(np.float64) / L)
+        got = resample_batch(_dev(xr, gpu), sr_in, sr_out).cpu().numpy()
+        assert got.shape == want.shape == (2, -(-n * L // M))
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-30), (n, sr_in, sr_out)
+        one = resample_batch(_dev(xr[1], gpu), sr_in, sr_out).cpu().numpy()
+        np.testing.assert_array_equal(one, got[1])
     # drop-in: a path at the file's own rate gives exactly what the array gives; a resampled path is close to it
     kw, y, exp = load_golden("refdefault_am")
     p = str(tmp_path / "clip.wav")
