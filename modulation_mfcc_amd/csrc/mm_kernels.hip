@@ -1447,7 +1447,8 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   const int64_t n1 = n_frames + 2 * q.p1, n2 = n_frames + 2 * q.p2;
   q.ws1 = (double*)d_ws; q.ws2 = q.ws1 + n1 * q.Rp; q.out = d_change;
   const int64_t tblocks = (n_frames + 63) / 64;
-  if (tblocks > 65535 || 2 * (int64_t)q.p1 * q.Rp / 256 + 1 > 0x7FFFFFFF || n_frames * q.Bp / 256 + 1 > 0x7FFFFFFF)
+  if (tblocks > 65535 || 2 * (int64_t)q.p1 * q.Rp / 256 + 1 > 0x7FFFFFFF || n_frames * q.Bp / 256 + 1 > 0x7FFFFFFF ||
+      q.Bp / 64 > 65535 || n_frames > 0x7FFFFFFF)
     return MM_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   StageTimer tm(p, MM_STAGE_CHANGE, st);
@@ -1455,7 +1456,10 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p1 * q.Rp + 255) / 256)), dim3(256), 0, st,
                      q.ws1, n_frames, q.p1, q.Rp);
   launch_sos_any(f1, q.ws1, n1, q.Rp, st);
-  hipLaunchKernelGGL(chg_norm_kernel, dim3((unsigned)((n_frames * q.Bp + 255) / 256)), dim3(256), 0, st, q);
+  if (q.n_rows <= MM_CHG_MAXROWS)
+    hipLaunchKernelGGL(chg_norm_kernel, dim3((unsigned)n_frames, (unsigned)(q.Bp / 64)), dim3(256), 0, st, q);
+  else
+    hipLaunchKernelGGL(chg_norm_rows_kernel, dim3((unsigned)((n_frames * q.Bp + 255) / 256)), dim3(256), 0, st, q);
   if (f2.n_sec > 0) {
     hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p2 * q.Bp + 255) / 256)), dim3(256), 0, st,
                        q.ws2, n_frames, q.p2, q.Bp);

@@ -5,6 +5,8 @@ that live on the GPU are filtered there (mm_sosfiltfilt_f64, mm_stencil_f64) -- 
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 from scipy import signal as _sig
 
@@ -50,10 +52,20 @@ def _validate(filt, cutOff, filtType, sr):
     return kind
 
 
+@functools.lru_cache(maxsize=64)
+def _iir_sos_cached(sr, cut, filtLen, kind):
+    sos = _sig.butter(filtLen, _band_edges(list(cut), sr, kind), btype=kind, output="sos")
+    return sos
+
+
 def iir_sos(sr, *, cutOff, filtLen=6, filtType="low"):
-    """The Butterworth sections applyFilter(filt='iir') would use (same checks, same exceptions)."""
+    """The Butterworth sections applyFilter(filt='iir') would use (same checks, same exceptions); the design is
+    kept per argument set (host arithmetic, scipy.signal.butter)."""
     kind = _validate("iir", cutOff, filtType, sr)
-    return _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
+    try:
+        return _iir_sos_cached(float(sr), tuple(float(c) for c in cutOff), int(filtLen), kind).copy()
+    except (TypeError, ValueError):
+        return _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
 
 
 def _is_device_tensor(x):

@@ -12,6 +12,8 @@ tap counts beyond that struct go through the host, filters._apply_filter_device)
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 from scipy import signal as _sig
 
@@ -24,9 +26,20 @@ def time_anchors(n_frames: int, tStep: float, winLen: float) -> np.ndarray:
     return np.round(k * tStep + winLen / 2, 4)
 
 
+@functools.lru_cache(maxsize=64)
+def _design_lowpass(filtOrd, filtCutoff, tStep):
+    sos = _sig.butter(filtOrd, filtCutoff / ((1 / tStep) / 2), btype="low", output="sos")
+    return sos
+
+
 def design_lowpass(filtOrd: int, filtCutoff: float, tStep: float) -> np.ndarray:
-    """script/mfcc.py:398-400: cutoff normalised by the frame-rate Nyquist (1/tStep)/2."""
-    return _sig.butter(filtOrd, filtCutoff / ((1 / tStep) / 2), btype="low", output="sos")
+    """script/mfcc.py:398-400: cutoff normalised by the frame-rate Nyquist (1/tStep)/2.  (The design is host
+    arithmetic -- scipy.signal.butter, ~0.1 ms -- and is kept per argument set: with it in every call the device
+    tail of 1024 clips would wait for the host.)"""
+    try:
+        return _design_lowpass(filtOrd, filtCutoff, tStep).copy()
+    except TypeError:          # unhashable arguments: design as the reference does, every time
+        return _sig.butter(filtOrd, filtCutoff / ((1 / tStep) / 2), btype="low", output="sos")
 
 
 def device_path_applies(diffMethod, outFilter) -> bool:

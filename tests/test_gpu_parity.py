@@ -713,6 +713,22 @@ def test_change_tail_on_device(kwargs, gpu):
         assert np.abs(got[i] - want).max() <= 1e-7 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("n_mfcc,B,T", [(80, 3, 400), (40, 70, 1001), (2, 5, 300)])
+def test_change_tail_many_rows_and_long_batches(n_mfcc, B, T, gpu):
+    """Row N1 beyond the reference's 13 coefficients: more rows per clip than the derivative kernel's LDS tile takes
+    (its row-walking variant), clip counts that are not a multiple of 64, the time-parallel IIR form (n >= 256) -- all
+    against scipy's sequential arithmetic."""
+    kw, _, _ = load_golden("c1_am")
+    plan = _plan(dict(kw, n_mels=128, n_mfcc=n_mfcc))
+    from modulation_mfcc_amd import tail
+    rng = np.random.default_rng(4)
+    m = rng.standard_normal((B, n_mfcc, T)).cumsum(axis=2).astype(np.float32)
+    got = tail.mfcc_change_device(plan, _dev(m, gpu), tStep=0.01, outFiltCutOff=[12]).cpu().numpy()
+    for i in (0, B // 2, B - 1):
+        want = O.mfcc_change_tail(m[i], tStep=0.01, outFiltCutOff=[12])
+        assert np.abs(got[i] - want).max() <= 1e-7 * np.abs(want).max()
+
+
 @pytest.mark.parametrize("filt,kw", [
     ("fir", dict(cutOff=[12.0], filtLen=6)), ("fir", dict(cutOff=[30.0], filtLen=2)),
     ("fir", dict(cutOff=[20.0], filtLen=7, filtType="high")), ("fir", dict(cutOff=[5.0, 40.0], filtLen=8, filtType="band")),
