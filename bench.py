@@ -176,6 +176,43 @@ def time_steps(torch, plan, fn, steps, warmup, stages, sync=None):
     return dt, stage
 
 
+def time_next_rows(torch, dev):
+    """Device times of the rows around the hot path at BASELINE-like sizes (ms per call, wall clock over 5 calls after
+    2 warm-up calls): N1 the MFCC-change tail of 1024 clips, N3 RMS and Hilbert envelopes, N4 PCM decode + 44.1 -> 16
+    kHz resampling of 256 ten-second clips."""
+    import ctypes as C
+    from modulation_mfcc_amd import MfccConfig, MfccPlan, tail, calc, audio_io, _lib
+    from modulation_mfcc_amd.batch import rms_batch
+
+    def t(fn, k=5):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / k * 1e3, 4)
+
+    out = {}
+    plan = MfccPlan(MfccConfig(**WORKLOADS["c3"][4]))
+    m = torch.randn((1024, 13, 1001), device=dev)
+    sos1 = tail.design_lowpass(6, 12, 0.01)
+    out["N1_change_tail_1024x13x1001_ms"] = t(lambda: plan.mfcc_change(m, sos1, sos1))
+    x = torch.randn((256, 160000), device=dev)
+    out["N3_rms_256x160000_ms"] = t(lambda: rms_batch(x, 400, 160, True))
+    out["N3_hilbert_256x160000_ms"] = t(lambda: calc.hilbert_envelope_batch(x))
+    x44 = torch.randn((256, 441000), device=dev)
+    out["N4_resample_44100_to_16000_256x441000_ms"] = t(lambda: audio_io.resample_batch(x44, 44100, 16000))
+    raw = torch.randint(0, 255, (256 * 441000 * 2 * 2,), dtype=torch.uint8, device=dev)
+    pcm = torch.empty((2, 256 * 441000), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out["N4_pcm_decode_s16_stereo_256x441000_ms"] = t(lambda: lib.mm_pcm_decode_f32(raw.data_ptr(), 2, 2, 256 * 441000, pcm.data_ptr(),
+                                                                                   256 * 441000, st))
+    return out
+
+
 def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=None, fused_tail=False):
     alg = {
         # unique audio in + log-mel out (+ the unclamped MFCC rows where the kernel also applies the DCT, + the
@@ -343,6 +380,14 @@ def main():
         (with the driver's 5 warmup steps = 2.5 ms alone, the 10 ms timed region falls into the clock ramp and reads
         15 % slow: 0.50 vs 0.43 ms per step on the same box)."""
         ex = {}
+        # ---- the rows either side of the hot path (SURVEY 8(f) N1 - N4), for the record (N = 1 only); FIRST: measured
+        # right before the headline region their double-precision kernels left it 10 % slower (0.49 vs 0.44 ms) ----
+        if world == 1:
+            try:
+                ex["next_rows"] = time_next_rows(torch, dev)
+            except Exception as e:          # never let a side measurement take the bench down
+                ex["next_rows"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
         # ---- stage-isolated batched rFFT (frames in -> complex bins out), same process ---------
         nrows = R * T
         frames_buf = torch.randn((nrows, cfg.n_fft), device=dev, dtype=torch.float32)
