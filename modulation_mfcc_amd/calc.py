@@ -227,7 +227,12 @@ def velocity_stencil(sr: float, difference: int = 1, method: str = "gradient", w
             pc = pc[:-1] * np.arange(pc.shape[0] - 1, 0, -1)[:, None] if pc.shape[0] > 1 else np.zeros((1, width))
         el = [[float(np.polyval(pc[:, j], i)) for j in range(width)] for i in range(half)]
         er = [[float(np.polyval(pc[:, j], width - half + i)) for j in range(width)] for i in range(half)]
-        return dict(off=list(range(-half, half + 1)), c=[float(v) for v in c], den_c=1.0, n_edge=half, edge_w=width,
+        # scipy's convolve1d puts an even kernel's centre at width // 2: as a correlation the taps sit on
+        # x[i - (width - 1) // 2 .. i + width // 2] (odd width: -half .. half; width 6, the reference's default
+        # outFiltLen: -2 .. 3)
+        off = list(range(-((width - 1) // 2), width // 2 + 1))
+        assert len(off) == len(c) == width
+        return dict(off=off, c=[float(v) for v in c], den_c=1.0, n_edge=half, edge_w=width,
                     el=el, er=er, den_e=1.0), 1
     if method == "finDiff":
         order, acc = int(difference), int(accOrder)
@@ -263,6 +268,8 @@ def apply_stencil(x2, st, passes: int = 1):
     from . import _lib
     rows, n = x2.shape
     cs = _lib.mm_stencil()
+    if len(st["off"]) != len(st["c"]):
+        raise ValueError("stencil: one offset per tap")
     cs.n_c, cs.n_edge, cs.edge_w = len(st["c"]), st["n_edge"], st["edge_w"]
     for k, (o, c) in enumerate(zip(st["off"], st["c"])):
         cs.off[k], cs.c[k] = o, c

@@ -693,6 +693,7 @@ def test_ragged_lengths_fast_and_generic(n, gpu):
     dict(outFilter="fir", outFiltCutOff=[12]), dict(outFilter="fir", outFiltType="high", outFiltCutOff=[5], outFiltLen=7),
     dict(outFilter="fir", outFiltType="band", outFiltCutOff=[2, 20], outFiltLen=8, diffMethod="sg"),
     dict(outFilter="sg", outFiltCutOff=[12], outFiltLen=7, outFiltPolyOrd=3),
+    dict(outFilter="sg", outFiltCutOff=[12]),        # the reference's defaults: outFiltLen 6 (EVEN window), outFiltPolyOrd 3
     dict(outFilter="sg", outFiltCutOff=[12], outFiltLen=15, outFiltPolyOrd=2, removeFirst=0),
     dict(outFilter="fir", outFiltCutOff=[12], outFiltLen=21),       # beyond the device stencil: host round trip
 ])
@@ -733,6 +734,8 @@ def test_change_tail_many_rows_and_long_batches(n_mfcc, B, T, gpu):
     ("fir", dict(cutOff=[12.0], filtLen=6)), ("fir", dict(cutOff=[30.0], filtLen=2)),
     ("fir", dict(cutOff=[20.0], filtLen=7, filtType="high")), ("fir", dict(cutOff=[5.0, 40.0], filtLen=8, filtType="band")),
     ("sg", dict(cutOff=[12.0], filtLen=5, polyOrd=3)), ("sg", dict(cutOff=[12.0], filtLen=13, polyOrd=2)),
+    ("sg", dict(cutOff=[12.0], filtLen=6, polyOrd=3)),      # even window: the reference's default outFiltLen / outFiltPolyOrd
+    ("sg", dict(cutOff=[12.0], filtLen=16, polyOrd=4)),
     ("iir", dict(cutOff=[12.0], filtLen=6)),
 ])
 def test_apply_filter_on_device(filt, kw, gpu):
@@ -762,6 +765,7 @@ def test_apply_filter_on_device(filt, kw, gpu):
     dict(method="gradient", difference=1), dict(method="gradient", difference=2),
     dict(method="sg", width=3, polyOrder=2, difference=1), dict(method="sg", width=7, polyOrder=3, difference=2),
     dict(method="sg", width=15, polyOrder=4, difference=1),
+    dict(method="sg", width=6, polyOrder=3, difference=1), dict(method="sg", width=4, polyOrder=2, difference=2),
     dict(method="finDiff", difference=1, accOrder=2), dict(method="finDiff", difference=2, accOrder=4),
     dict(method="finDiff", difference=1, accOrder=6),
 ])

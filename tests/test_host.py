@@ -216,6 +216,10 @@ def test_fir_filtfilt_stencil_on_the_host(n_taps, kind, cut):
     dict(method="gradient", difference=1), dict(method="gradient", difference=2),
     dict(method="sg", width=3, polyOrder=2, difference=1), dict(method="sg", width=7, polyOrder=3, difference=2),
     dict(method="sg", width=11, polyOrder=2, difference=1), dict(method="sg", width=9, polyOrder=3, difference=0),
+    # even windows (scipy centres them at width // 2): 6 / 3 is the reference's default outFiltLen / outFiltPolyOrd
+    dict(method="sg", width=6, polyOrder=3, difference=0), dict(method="sg", width=6, polyOrder=3, difference=1),
+    dict(method="sg", width=4, polyOrder=2, difference=1), dict(method="sg", width=8, polyOrder=3, difference=2),
+    dict(method="sg", width=16, polyOrder=4, difference=0),
     dict(method="finDiff", difference=1, accOrder=2), dict(method="finDiff", difference=2, accOrder=4),
     dict(method="finDiff", difference=1, accOrder=6),
 ])
@@ -229,6 +233,7 @@ def test_velocity_stencils_on_the_host(kw):
     x = rng.standard_normal(200).cumsum()
     st, passes = velocity_stencil(200.0, **kw)
     assert len(st["c"]) <= 16 and st["n_edge"] <= 8 and st["edge_w"] <= 16
+    assert len(st["off"]) == len(st["c"])
     y = x
     for _ in range(passes):
         y = _stencil_numpy(st, y)
