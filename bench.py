@@ -52,17 +52,36 @@ def workload_label(name, B, T, cfg, n_mod):
             + (f" + modulation spectrum (rFFT {n_mod} over trajectories)" if with_mod else ""))
 
 
+def csrc_sha16():
+    """Content hash of the kernel sources (csrc/* and the C header), 16 hex digits: what ties a committed counter
+    summary to the code it was taken on (tools/summarize_prof.py writes the same value into profiles/*_pmc.csv)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "modulation_mfcc_amd", "csrc")
+    files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".inc", ".h", ".cpp")) or f == "Makefile")
+    files.append(os.path.join(ROOT, "include", "modmfcc.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary that lists it
     (profiles/*_pmc.csv, written by tools/summarize_prof.py from separate FETCH_SIZE / WRITE_SIZE passes of
-    this same command; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes).  None if absent."""
+    this same command; FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes) -- but ONLY a summary taken on the kernel
+    sources of this run (its csrc_sha16 column equals csrc_sha16()): otherwise None, with the reason."""
     import csv
     import glob
+    want = csrc_sha16()
+    stale = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")), reverse=True):
         for r in csv.DictReader(open(f)):
             if kernel_key in r["Kernel"]:
-                return int(r["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
-    return None, None
+                if r.get("csrc_sha16") == want:
+                    return int(r["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+                stale = stale or os.path.relpath(f, ROOT)
+    return None, (f"no counter summary for csrc {want} (newest listing this kernel: {stale}, other sources)" if stale else None)
 
 
 def synth_batch(torch, device, batch, n, sr, seed0):
@@ -135,6 +154,24 @@ def cpu_baseline(kw, n, with_mod, budget_s=12.0):
                       f"1 thread, {dt:.1f} s wall, {busy:.0f} core-seconds in the path"}
 
 
+def _check_one(args):
+    seed, n, kw, with_mod = args
+    import mfcc_oracle as O
+    clip = O.synth_clip(seed, n, kw["sr"], "am")
+    m = O.mfcc(clip, O.OracleConfig(**kw))
+    return clip, m, (O.modspec(m) if with_mod else None)
+
+
+def oracle_check_vectors(kw, n, with_mod, seeds=(90001, 90002, 90003)):
+    """Three clips of the run's signal model with their oracle MFCCs (and modulation spectra), computed in forked
+    workers BEFORE this process touches HIP -- the oracle as the checker of the timed output, never on its path.  main()
+    writes the clips into rows 0, R/2 and R-1 of the device batch and compares those output rows after the timed region."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    with ctx.Pool(len(seeds), initializer=_cpu_init) as pool:
+        return pool.map(_check_one, [(sd, n, kw, with_mod) for sd in seeds])
+
+
 EVENT_EVERY = 4      # dominant-kernel HIP events on every 4th timed step
 
 
@@ -176,10 +213,15 @@ def time_steps(torch, plan, fn, steps, warmup, stages, sync=None):
     return dt, stage
 
 
+FP32_VEC_TF = 157.3           # MI355X_MICROARCH.md: peak FP32 vector = peak f32-input MFMA
+FP64_VEC_TF = 78.6            # FP64 vector (half the FP32 vector rate)
+
+
 def time_next_rows(torch, dev):
-    """Device times of the rows around the hot path at BASELINE-like sizes (ms per call, wall clock over 5 calls after
-    2 warm-up calls): N1 the MFCC-change tail of 1024 clips, N3 RMS and Hilbert envelopes, N4 PCM decode + 44.1 -> 16
-    kHz resampling of 256 ten-second clips."""
+    """The rows around the hot path at BASELINE-like sizes: device time per call (wall clock over
+    5 calls after 2 warm-up calls) WITH what bounds each -- algorithmic bytes (what the row must read + write) against
+    the 8 TB/s HBM peak, or algorithmic flops against the matching arithmetic peak -- so that every entry carries a
+    fraction of a roofline, not a bare time."""
     import ctypes as C
     from modulation_mfcc_amd import MfccConfig, MfccPlan, tail, calc, audio_io, _lib
     from modulation_mfcc_amd.batch import rms_batch
@@ -192,36 +234,67 @@ def time_next_rows(torch, dev):
         for _ in range(k):
             fn()
         torch.cuda.synchronize()
-        return round((time.perf_counter() - t0) / k * 1e3, 4)
+        return (time.perf_counter() - t0) / k * 1e3
+
+    def hbm(ms, nbytes, what):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"ms": round(ms, 4), "bound": "hbm", "algorithmic_bytes": int(nbytes), "achieved": round(gbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_are": what}
+
+    def flops(ms, nflop, peak, which, what):
+        tf = nflop / (ms * 1e-3) / 1e12
+        return {"ms": round(ms, 4), "bound": which, "algorithmic_flops": int(nflop), "achieved": round(tf, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "flops_are": what}
 
     out = {}
     plan = MfccPlan(MfccConfig(**WORKLOADS["c3"][4]))
-    m = torch.randn((1024, 13, 1001), device=dev)
+    B, K, T = 1024, 13, 1001
+    m = torch.randn((B, K, T), device=dev)
     sos1 = tail.design_lowpass(6, 12, 0.01)
-    out["N1_change_tail_1024x13x1001_ms"] = t(lambda: plan.mfcc_change(m, sos1, sos1))
+    ms = t(lambda: plan.mfcc_change(m, sos1, sos1))
+    out["N1_change_tail_1024x13x1001"] = hbm(ms, B * K * T * 4 + B * T * 8, "MFCC rows in (f32) + change curve out (f64); the "
+                                             "float64 recursion is latency-bound, DESIGN.md section 7")
     x = torch.randn((256, 160000), device=dev)
-    out["N3_rms_256x160000_ms"] = t(lambda: rms_batch(x, 400, 160, True))
-    out["N3_hilbert_256x160000_ms"] = t(lambda: calc.hilbert_envelope_batch(x))
+    ms = t(lambda: rms_batch(x, 400, 160, True))
+    out["N3_rms_256x160000"] = hbm(ms, 256 * 160000 * 4 + 256 * 1001 * 4, "samples in + envelope out")
+    ms = t(lambda: calc.hilbert_envelope_batch(x))
+    out["N3_hilbert_256x160000"] = hbm(ms, 256 * 160000 * 8, "samples in + envelope out (the four fused FFT passes of "
+                                       "the implementation move 8x that: 2.6 GB)")
+    out["N3_hilbert_256x160000"]["implementation_bytes"] = 256 * 160000 * 8 * 2 * 4
     x44 = torch.randn((256, 441000), device=dev)
-    out["N4_resample_44100_to_16000_256x441000_ms"] = t(lambda: audio_io.resample_batch(x44, 44100, 16000))
+    ms = t(lambda: audio_io.resample_batch(x44, 44100, 16000))
+    L, M = audio_io.resample_ratio(44100, 16000)
+    h, _ = audio_io.design_taps(L, M)
+    tpo = -(-len(h) // L)                               # taps per output sample
+    n_out = -(-441000 * L // M)
+    out["N4_resample_44100_to_16000_256x441000"] = flops(
+        ms, 2.0 * tpo * n_out * 256, FP32_VEC_TF, "fp32-matrix",
+        f"2 x {tpo} taps per output x {n_out} outputs x 256 clips (polyphase FIR {L}/{M}, {len(h)} taps)")
+    out["N4_resample_44100_to_16000_256x441000"]["hbm"] = hbm(ms, 256 * (441000 + n_out) * 4, "samples in + samples out")
     raw = torch.randint(0, 255, (256 * 441000 * 2 * 2,), dtype=torch.uint8, device=dev)
     pcm = torch.empty((2, 256 * 441000), dtype=torch.float32, device=dev)
     lib = _lib.load()
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    out["N4_pcm_decode_s16_stereo_256x441000_ms"] = t(lambda: lib.mm_pcm_decode_f32(raw.data_ptr(), 2, 2, 256 * 441000, pcm.data_ptr(),
-                                                                                   256 * 441000, st))
+    ms = t(lambda: lib.mm_pcm_decode_f32(raw.data_ptr(), 2, 2, 256 * 441000, pcm.data_ptr(), 256 * 441000, st))
+    out["N4_pcm_decode_s16_stereo_256x441000"] = hbm(ms, 256 * 441000 * 2 * (2 + 4), "interleaved s16 in + planar f32 out")
     return out
 
 
 def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=None, fused_tail=False):
+    spec_rows = 8 * (n_mod // 2 + 1) * cfg.n_mfcc / T if fused_tail else 0
+    # ALGORITHMIC bytes of what the launch computes -- a kernel that goes from samples to MFCCs (the
+    # fused DCT) counts unique audio in + MFCC out (+ the modulation-spectrum rows where the whole tail runs in the
+    # launch): 4 hop + 4 n_mfcc (+ spectrum) = 692 (745) B/frame at configs[1] ([2]); a kernel that stops at the
+    # log-mel rows counts audio in + log-mel out.  What the IMPLEMENTATION moves on top (the log-mel rows the fused
+    # kernel still stores for the rare clamp fix-up) is reported beside it, never in `frac`.
     alg = {
-        # unique audio in + log-mel out (+ the unclamped MFCC rows where the kernel also applies the DCT, + the
-        # modulation-spectrum rows where the whole tail runs in the launch)
-        "logmel": 4 * cfg.hop_length + 4 * cfg.n_mels + (4 * cfg.n_mfcc if fused_dct else 0)
-                  + (8 * (n_mod // 2 + 1) * cfg.n_mfcc / T if fused_tail else 0),
+        "logmel": 4 * cfg.hop_length + (4 * cfg.n_mfcc if fused_dct else 4 * cfg.n_mels) + spec_rows,
         "dct": 4 * cfg.n_mels + 4 * cfg.n_mfcc,            # log-mel in + MFCC out
         "modspec": (4 * T + 8 * (n_mod // 2 + 1)) * cfg.n_mfcc / T if with_mod else 0,
     }
+    impl = dict(alg)
+    impl["logmel"] = 4 * cfg.hop_length + 4 * cfg.n_mels + (4 * cfg.n_mfcc if fused_dct else 0) + spec_rows \
+        + (4 * cfg.n_mfcc if fused_tail else 0)            # + the MFCC rows read back by the in-launch trajectory rFFT
     dom = max(per_stage, key=lambda k: per_stage[k]["avg_ms"])
     if dom not in alg:
         return None
@@ -231,6 +304,7 @@ def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=No
     out = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
            "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_frame": alg[dom],
+           "implementation_bytes_per_frame": impl[dom],
            "avg_launch_ms": per_stage[dom]["avg_ms"], "launches_timed": per_stage[dom]["launches"]}
     if dom == "logmel":
         # for information: the fused kernel is issue / LDS bound, not HBM bound -- its
@@ -252,6 +326,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--clips", type=int, default=0, help="override clips per GPU (debug)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle spot-check of three output clips")
     ap.add_argument("--no-extra", action="store_true", help="skip the c2 / c4 / rFFT-stage passes (profiling runs)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernels")
     ap.add_argument("--no-fuse-tail", action="store_true", help="separate launches for the clamp fix-up and the trajectory rFFT (development A/B)")
@@ -289,6 +364,9 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not a.no_cpu:
         cpu = cpu_baseline(kw, int(secs * kw["sr"]), with_mod)      # no torch / HIP yet in this process
+    check_vec = None
+    if rank == 0 and not a.no_check:
+        check_vec = oracle_check_vectors(kw, int(secs * kw["sr"]), with_mod)
 
     import torch
     import torch.distributed as dist
@@ -323,6 +401,10 @@ def main():
     cfg, plan, audio, n, T = make(a.workload, a.clips)
     rows = audio.reshape(-1, n)
     R = rows.shape[0]
+    check_rows = sorted({0, R // 2, R - 1})
+    if check_vec is not None:           # three rows of the timed batch carry clips whose oracle answer is known
+        for r_, (clip_, _, _) in zip(check_rows, check_vec):
+            rows[r_].copy_(torch.from_numpy(clip_))
 
     # one flat output slab per rank so that a single gather per step moves everything; with N > 1
     # the slabs are double-buffered and the gather of step k runs on a side stream under the
@@ -337,6 +419,9 @@ def main():
         mod_on_root = use_dist and with_mod and gather_mode == "mfcc"
         lay = SlabLayout.make(cfg, R, n, with_mod and not mod_on_root)
         pg = PipelinedGather(lay.numel, dev) if use_dist else None
+        if pg:
+            pg.time_every(EVENT_EVERY)
+        last = {}
         slab1 = torch.empty(lay.numel, dtype=torch.float32, device=dev) if not use_dist else None
         mod_all = None
         if mod_on_root and rank == 0:
@@ -350,6 +435,7 @@ def main():
         def step():
             slab = pg.acquire() if pg else slab1
             mfcc_out, mod_out = lay.views(slab)
+            last["mfcc"], last["mod"] = mfcc_out, mod_out
             if with_mod and not mod_on_root:
                 plan.mfcc_modspec(rows, out=mfcc_out, out_mod=mod_out)    # one launch where the plan can (fused tail)
             else:
@@ -363,16 +449,33 @@ def main():
             if use_dist:
                 dist.barrier()
 
-        dt, stage = time_steps(torch, plan, step, steps, warmup, ["logmel"], sync=drain)
+        if pg:
+            for _ in range(warmup):
+                step()
+            drain()
+            pg.gather_ms()              # discard the warm-up gathers' events (communicator set-up is in the first one)
+            dt, stage = time_steps(torch, plan, step, steps, 0, ["logmel"], sync=drain)
+        else:
+            dt, stage = time_steps(torch, plan, step, steps, warmup, ["logmel"], sync=drain)
+        per_rank = None
         if use_dist:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+            # per rank: device time of the step's kernels (HIP events, every EVENT_EVERY-th step) and of its gather as
+            # the side stream saw it -- what separates "compute" from "wire" in the scaling curve
+            g_ms, g_n = pg.gather_ms()
+            c_ms = sum(v[0] / v[1] for v in stage.values() if v[1])
+            mine = torch.tensor([c_ms, g_ms, float(g_n)], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [{"rank": i, "compute_ms": round(float(v[0]), 4), "gather_ms": round(float(v[1]), 4),
+                         "gathers_timed": int(v[2])} for i, v in enumerate(allr)]
         if pg is not None and rank == 0 and os.environ.get("MM_BENCH_FORCE_DIST"):
             # rehearsal check: what arrived at the root is what the last steps produced
             last = (pg.k - 1) % pg.depth
             assert torch.equal(pg.received[last][0], pg.slabs[last]), "gathered slab differs"
-        return dt, stage, mod_on_root
+        return dt, stage, mod_on_root, last, per_rank, lay
 
     def run_extras():
         """The bench's other sections -- stage-isolated rFFT, device copy, BASELINE configs[1] and configs[3] -- run
@@ -452,7 +555,23 @@ def main():
         return ex
 
     extras = run_extras() if not a.no_extra else {}
-    dt, stage, mod_on_root = run_variant(a.gather, a.steps, a.warmup)
+    dt, stage, mod_on_root, last, per_rank, lay = run_variant(a.gather, a.steps, a.warmup)
+    # ---- spot-check of the TIMED output against the oracle, outside the timed region: the three rows that carry the
+    # oracle's clips, MFCC (north-star bound: 1e-4 of max|MFCC|) and modulation spectrum ----
+    check = None
+    if check_vec is not None and rank == 0:
+        import numpy as np
+        worst, worst_ms = 0.0, 0.0
+        for r_, (_, want, want_ms) in zip(check_rows, check_vec):
+            got = last["mfcc"][r_].cpu().numpy()
+            worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+            if want_ms is not None and last["mod"] is not None:
+                gm = last["mod"][r_].cpu().numpy()
+                worst_ms = max(worst_ms, float(np.abs(gm - want_ms).max() / np.abs(want_ms).max()))
+        check = {"rows": check_rows, "max_rel": worst, "max_rel_modspec": (worst_ms if last["mod"] is not None else None),
+                 "tolerance": 1e-4, "ok": bool(worst <= 1e-4 and worst_ms <= 1e-4),
+                 "against": "NumPy oracle (oracle/mfcc_oracle.py) on the same three clips, computed before HIP init; "
+                            "output rows of the last timed step"}
     frames_total = world * R * T * a.steps
     res = {
         "metric": "MFCC+mod-spectrum frames/sec" if with_mod else "MFCC frames/sec",
@@ -464,11 +583,14 @@ def main():
                    "parallelism": f"clips sharded x{world}" + (", one RCCL gather per step (overlapped with the next step's kernels)" if world > 1 else "")
                                   + ("; MFCC slab gathered, modulation spectrum of the gathered trajectories computed on the root" if mod_on_root else ""),
                    "gather": (a.gather if use_dist else None),
+                   "rccl_ranks": (dist.get_world_size() if use_dist else None),
+                   "gather_bytes_per_rank": (lay.numel * 4 if use_dist else None),
+                   "csrc_sha16": csrc_sha16(),
                    "hsa_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
     }
     if use_dist and with_mod:
         other = "full" if a.gather == "mfcc" else "mfcc"
-        dt2, _, _ = run_variant(other, max(3, a.steps // 2), 2)
+        dt2 = run_variant(other, max(3, a.steps // 2), 2)[0]
         k2 = max(3, a.steps // 2)
         if rank == 0:
             res["gather_other"] = {"gather": other, "value": world * R * T * k2 / dt2, "unit": "frames/s",
@@ -499,6 +621,10 @@ def main():
         if "_copy_gbs" in extras and "roofline" in res:
             res["roofline"]["device_copy_GBs"] = extras["_copy_gbs"]
 
+        if per_rank is not None:
+            res["per_rank"] = per_rank
+        if check is not None:
+            res["check"] = check
         if cpu is not None:
             res["cpu_baseline"] = cpu
         sys.stdout.flush()

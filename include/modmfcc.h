@@ -33,7 +33,12 @@
  *   - every compute call is asynchronous on the caller's hipStream_t (passed as void*), does
  *     no allocation and no synchronisation (graph-capture safe);
  *   - functions return MM_OK (0) or a negative mm_status; nothing throws, nothing exits;
- *   - a plan is immutable after creation and bound to the device current at creation.
+ *   - a plan is bound to the device current at creation.  Its constant tables never change after mm_plan_create;
+ *     the few SET-UP calls that do change plan state -- mm_plan_set_variant, mm_plan_set_fuse_dct,
+ *     mm_plan_set_fuse_tail, mm_plan_force_generic, mm_timing_enable / mm_timing_read -- are unsynchronised
+ *     host-side switches: call them from the thread that owns the plan, between compute calls, never while another
+ *     thread is inside a compute call on the same plan.  A plan that is only computed with (no set-up calls, timing
+ *     off) may be shared by threads that each pass their own buffers, workspace and stream.
  */
 #ifndef MODMFCC_H
 #define MODMFCC_H
@@ -234,12 +239,16 @@ int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t a
 
 /* Hilbert envelope (row N3): np.abs(scipy.signal.hilbert(x)) as called at script/calc.py:286 -- the DFT of the
  * clip at its own length n (any integer 1 .. 2^24), negative frequencies zeroed, positive ones doubled, the
- * inverse DFT, the magnitude -- for a batch of clips of one length.  Both DFTs are Bluestein chirp-z transforms
- * over power-of-two Stockham FFTs of mm_hilbert_fft_size() points (n a power of two >= 16: the FFT itself), in
- * the clips' own precision like scipy (dtype 0: float32 / complex64, 1: float64 / complex128).
+ * inverse DFT, the magnitude -- for a batch of clips of one length.  A length of the form 2^a 3^b 5^c 7^d (>= 16:
+ * sample counts such as 160 000, 441 000, 480 000) is transformed DIRECTLY by the library's mixed-radix Stockham FFT
+ * (radix 16 / 8 / 4 / 2 / 9 / 3 / 25 / 5 / 49 / 7 passes, pairs of radix-16 or radix-25 passes fused into one
+ * launch): mm_hilbert_fft_size() == n.  Any other length goes through Bluestein's chirp-z identity over a
+ * power-of-two FFT of mm_hilbert_fft_size() = M >= 2n - 1 points.  Transforms run in the clips' own precision like
+ * scipy (dtype 0: float32 / complex64, 1: float64 / complex128).
  * mm_hilbert_create allocates and fills the constant device tables on the current device (and synchronises);
  * mm_hilbert_envelope is asynchronous on `stream`: d_x [rows][x_stride] -> d_env [rows][env_stride], rows <=
- * 65535 per call, workspace = mm_hilbert_workspace_bytes(rows) = two [rows][fft_size] complex buffers. */
+ * 65535 per call, workspace = mm_hilbert_workspace_bytes(rows) = two [rows][fft_size] complex buffers -- size it with
+ * that call, not from n (fft_size is n on the direct path, M on the Bluestein path). */
 typedef struct mm_hilbert mm_hilbert;
 int mm_hilbert_create(int64_t n, int32_t dtype, mm_hilbert** out);
 void mm_hilbert_destroy(mm_hilbert* h);

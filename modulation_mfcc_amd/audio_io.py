@@ -43,8 +43,13 @@ def read_wav_header(path):
             cid, size = ck[:4], struct.unpack("<I", ck[4:])[0]
             if cid == b"fmt ":
                 body = f.read(size + (size & 1))
+                if size < 16 or len(body) < 16:
+                    raise ValueError(f"{path}: truncated fmt chunk ({size} bytes)")
                 tag, ch, sr, _, align, bits = struct.unpack("<HHIIHH", body[:16])
-                if tag == 0xFFFE and size >= 40:
+                if tag == 0xFFFE and size >= 40 and len(body) >= 26:
+                    # WAVE_FORMAT_EXTENSIBLE: wValidBitsPerSample (body[18:20]) may be smaller than the container
+                    # `bits`; samples are MSB-justified in the container, and -- like libsndfile -- the decode scales
+                    # by the CONTAINER width, so e.g. 20 valid bits in a 24-bit container come out at the same level
                     tag = struct.unpack("<H", body[24:26])[0]        # first two bytes of the sub-format GUID
                 fmt = (tag, ch, sr, align, bits)
             elif cid == b"data":
@@ -122,13 +127,21 @@ def design_taps(L: int, M: int, passband: float = PASSBAND, stop_db: float = STO
     return h * (L / h.sum()), half_len
 
 
-_TAPS = {}
+import collections
+
+_TAPS = collections.OrderedDict()      # (L, M, device) -> device taps, least recently used first
+TAPS_MAX = 8                           # a 44.1 -> 10 kHz design is ~83 k taps; unusual rate pairs must not pile up
 
 
 def _device_taps(L, M, dev):
     import torch
     key = (L, M, str(dev))
-    if key not in _TAPS:
+    if key in _TAPS:
+        _TAPS.move_to_end(key)
+    else:
+        while len(_TAPS) >= TAPS_MAX:
+            torch.cuda.synchronize(dev)          # nothing in flight may still read the evicted table
+            _TAPS.popitem(last=False)
         h, half = design_taps(L, M)
         tpp = -(-(-(-len(h) // L)) // 4) * 4                # taps per output, padded to a multiple of 4 with zeros
         hp = np.zeros((L, tpp), dtype=np.float32)          # polyphase order: hp[p][j] = h[p + j L]

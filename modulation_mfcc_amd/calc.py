@@ -54,9 +54,10 @@ def hilbert_envelope_batch(x):
     on the device, in scipy's arithmetic: DFT of length N = len(x) in the input's precision, negative
     frequencies zeroed / positive ones doubled, inverse DFT, magnitude (script/calc.py:286).
 
-    N is the clip length, an arbitrary integer (160 000 = 2^8 * 5^4 for a 10 s clip): both DFTs are Bluestein
-    chirp-z transforms over the library's own power-of-two Stockham FFT (mm_hilbert_envelope,
-    csrc/mm_hilbert.hip.inc); the constant tables of a length are built once and kept."""
+    N is the clip length, an arbitrary integer: lengths of the form 2^a 3^b 5^c 7^d (160 000 = 2^8 * 5^4 for a 10 s
+    clip, 441 000, 480 000 ...) are transformed directly by the library's mixed-radix Stockham FFT, any other length
+    through Bluestein's chirp-z identity over a power-of-two FFT (mm_hilbert_envelope, csrc/mm_hilbert.hip.inc);
+    the constant tables of a length are built once and kept (LRU of HILBERT_MAX_PLANS lengths)."""
     import ctypes as C
     import torch
     from . import _lib

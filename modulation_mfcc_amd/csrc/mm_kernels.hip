@@ -24,6 +24,7 @@
 #include <new>
 
 #include "mm_internal.h"
+#include "mm_dev.h"
 
 #define MM_TW_N 8192  // master twiddle table: exp(-2 pi i k / 8192), k < 8192 (full circle)
 
@@ -913,15 +914,6 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   *out = p;
   return MM_OK;
 }
-
-#ifdef MM_STAMP
-extern "C" int mm_debug_stamps(unsigned int* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm_stamp_acc), sizeof(unsigned int) * 256) == hipSuccess ? 0 : -1;
-}
-extern "C" int mm_debug_fin_stamps(unsigned int* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mm_fin_acc), sizeof(unsigned int) * 128) == hipSuccess ? 0 : -1;
-}
-#endif
 
 int mm_plan_destroy(mm_plan* p) {
   if (!p) return MM_OK;

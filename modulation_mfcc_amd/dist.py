@@ -115,6 +115,19 @@ class PipelinedGather:
         self.ev_ready = [torch.cuda.Event() for _ in range(depth)]    # kernels of buffer i finished
         self.k = 0
         self._used = [False] * depth
+        self._timed = []               # (start, end) event pairs on the side stream, see time_every()
+        self._time_every = 0
+
+    def time_every(self, every: int):
+        """Record an event pair around every ``every``-th gather on the side stream (0 = off); gather_ms() reads them."""
+        self._time_every = int(every)
+
+    def gather_ms(self):
+        """(average ms, count) of the timed gathers on this rank -- the collective as this rank's side stream saw it
+        (a sender's time is its own send; the root's spans the receipt of every peer's slab).  Synchronises."""
+        ms = [a.elapsed_time(b) for a, b in self._timed if (b.synchronize() or True)]
+        self._timed = []
+        return (sum(ms) / len(ms) if ms else 0.0), len(ms)
 
     def acquire(self):
         import torch
@@ -132,7 +145,14 @@ class PipelinedGather:
         self.ev_ready[i].record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(self.ev_ready[i])
+            timed = self._time_every and self.k % self._time_every == 0
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
             gather_slabs(self.slabs[i], dst=self.dst, group=self.group, out=self.received[i])
+            if timed:
+                e1.record(self.stream)
+                self._timed.append((e0, e1))
             if post is not None and self.rank == self.dst:
                 post(i)
             self.ev_done[i].record(self.stream)

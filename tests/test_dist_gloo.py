@@ -17,12 +17,24 @@ def test_shard_bounds():
     assert b[0][0] == 0 and b[-1][1] == 1001 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
 
 
+def _run_world(world, n_clips, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_dist_worker.py"), str(n_clips)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for rank in range(world):
+        assert f"rank {rank} ok" in r.stdout
+
+
 @pytest.mark.parametrize("n_clips", [5, 2, 1])
 def test_sharded_gather_world2(n_clips):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(29600 + n_clips),
-           os.path.join(ROOT, "tests", "_dist_worker.py"), str(n_clips)]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    _run_world(2, n_clips, 29600 + n_clips)
+
+
+@pytest.mark.parametrize("n_clips", [1, 5])
+def test_sharded_gather_world4(n_clips):
+    """Four ranks: n_clips 1 leaves three ranks EMPTY (shard_bounds(1, 4)), n_clips 5 gives shards of 2 / 1 / 1 / 1 --
+    the padded equal-size slabs, the per-rank counts and the root-side concatenation with empty and uneven ranks."""
+    _run_world(4, n_clips, 29620 + n_clips)

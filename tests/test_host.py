@@ -144,6 +144,12 @@ def test_wav_header_parser(tmp_path):
     bad.write_bytes(b"RIFF\x04\x00\x00\x00WAVX")
     with pytest.raises(ValueError, match="not a RIFF/WAVE"):
         read_wav_header(str(bad))
+    import struct
+    short = tmp_path / "short_fmt.wav"                       # a fmt chunk of 8 bytes: ValueError, not struct.error
+    body = b"WAVE" + b"fmt " + struct.pack("<I", 8) + b"\x01\x00\x01\x00\x22\x56\x00\x00" + b"data" + struct.pack("<I", 4) + b"\0\0\0\0"
+    short.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    with pytest.raises(ValueError, match="truncated fmt chunk"):
+        read_wav_header(str(short))
 
 
 @pytest.mark.parametrize("sr_in,sr_out", [(48000, 16000), (44100, 16000), (44100, 10000), (16000, 10000), (8000, 16000)])

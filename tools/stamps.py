@@ -1,4 +1,4 @@
-"""dev helper: build a side copy with -DMM_STAMP (tools/build_ru.sh style, -o ../libmodmfcc_stamp.so) and point MODMFCC_LIB at it; runs the fused kernel, print per-section cycle totals of workgroup 0.
+"""dev helper: build a side copy with -DMM_DEV (`make -C modulation_mfcc_amd/csrc dev` -> libmodmfcc_dev.so) and point MODMFCC_LIB at it; runs the fused kernel, print per-section cycle totals of workgroup 0.
 Sections: 0 window (+wait for samples)  1 DFT-16 #1  2 twiddles  3 exchange + DFT-16 #2  4 split + power rows
 5 prefetch issue  6 barrier A->B  7 phase B  8 barrier B->A  9 loop top  10 exchange (then 3 = DFT-16 #2 alone)
 w16s: 11 staging loads issued, 0 S reads + window, 5 staging store (after barrier A->B)"""

@@ -1,4 +1,4 @@
-"""dev helper: like tools/stamps.py for the clip-mode finalisation (s16_finalize_all): build with -DMM_STAMP into
+"""dev helper: like tools/stamps.py for the clip-mode finalisation (s16_finalize_all): build with -DMM_DEV into
 ../libmodmfcc_stamp.so, MODMFCC_LIB=that; prints cycles per launch (workgroup 0, all of a wave's row pairs), per wave:
 row loads arrived | DFT-16 #1 + twiddles + exchange | DFT-16 #2 (+ radix-2) | split + stores issued  (waves 0-6)"""
 import sys, ctypes, os

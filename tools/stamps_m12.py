@@ -1,4 +1,4 @@
-"""dev: per-wave s_memtime totals of the m12 kernel's loop sections (workgroup 0); needs a -DMM_STAMP build
+"""dev: per-wave s_memtime totals of the m12 kernel's loop sections (workgroup 0); needs a -DMM_DEV build
 (MODMFCC_LIB).  Sections: 0 S reads + barrier B | 1 DMA issue | 2 mel (rank 0) | 3 window + DFT-16 + twiddles
 | 4 mel (rank 1) | 5 exchange | 6 mel (rank 2) | 7 DFT-16 #2 + split + power rows | 8 vmcnt wait | 9 barrier A"""
 import sys, ctypes, os

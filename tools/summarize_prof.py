@@ -27,7 +27,7 @@ def main(src, prefix):
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
     rows = list(csv.DictReader(open(stats)))
-    ours = ("logmel512", "logmel12m", "logmel_wpf", "stft_generic", "dct_clamp", "dct_fixup", "rfft16", "rfft_wpf", "rfft_generic", "mfcc_change", "decode_keys", "devcopy")
+    ours = ("logmel512", "logmel12m", "logmel_wpf", "stft_generic", "stft_any", "dct_clamp", "dct_fixup", "rfft16", "rfft_wpf", "rfft_generic", "mfcc_change", "decode_keys", "devcopy", "resample", "hb_pass", "chg_", "pcm_decode", "rms_tile")
     with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
@@ -48,15 +48,25 @@ def main(src, prefix):
         bench = json.load(open(os.path.join(src, "bench_trace.json")))
     except Exception:
         pass
+    # the kernel sources the counters were taken on: bench.py stamps its JSON with a content hash of csrc/ (computed on
+    # the GPU box, from the snapshot that ran); bench.py's pmc_traffic() only trusts a summary whose stamp equals the
+    # hash of the sources it runs on
+    shas = set()
+    for jf in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
+        try:
+            shas.add(json.load(open(os.path.join(src, jf)))["config"]["csrc_sha16"])
+        except Exception:
+            pass
+    sha = shas.pop() if len(shas) == 1 else "unknown"
     with open(prefix + "_pmc.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Kernel", "launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg",
-                    "read_bytes_corrected(x2)", "write_bytes", "hbm_bytes_per_launch"])
+                    "read_bytes_corrected(x2)", "write_bytes", "hbm_bytes_per_launch", "csrc_sha16"])
         for k, v in sorted(pmc.items()):
             fe = sum(v.get("FETCH_SIZE", [0])) / max(1, len(v.get("FETCH_SIZE", [0])))
             wr = sum(v.get("WRITE_SIZE", [0])) / max(1, len(v.get("WRITE_SIZE", [0])))
             w.writerow([k, len(v.get("FETCH_SIZE", [])), f"{fe:.1f}", f"{wr:.1f}",
-                        int(2 * fe * 1024), int(wr * 1024), int(2 * fe * 1024 + wr * 1024)])
+                        int(2 * fe * 1024), int(wr * 1024), int(2 * fe * 1024 + wr * 1024), sha])
     if bench:
         with open(prefix + "_bench.json", "w") as f:
             json.dump(bench, f, indent=1)
