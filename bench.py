@@ -473,8 +473,8 @@ def main():
                          "gathers_timed": int(v[2])} for i, v in enumerate(allr)]
         if pg is not None and rank == 0 and os.environ.get("MM_BENCH_FORCE_DIST"):
             # rehearsal check: what arrived at the root is what the last steps produced
-            last = (pg.k - 1) % pg.depth
-            assert torch.equal(pg.received[last][0], pg.slabs[last]), "gathered slab differs"
+            li = (pg.k - 1) % pg.depth
+            assert torch.equal(pg.received[li][0], pg.slabs[li]), "gathered slab differs"
         return dt, stage, mod_on_root, last, per_rank, lay
 
     def run_extras():

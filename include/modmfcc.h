@@ -50,12 +50,12 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 114 /* 0.2.4 */
+#define MM_VERSION 120 /* 0.3.0 */
 
 typedef enum mm_status {
   MM_OK = 0,
   MM_ERR_INVALID_ARG = -1,  /* NULL pointer, non-positive size, fmax <= fmin ...              */
-  MM_ERR_UNSUPPORTED = -2,  /* n_fft not a power of two in [32, 4096], center == 0 ...        */
+  MM_ERR_UNSUPPORTED = -2,  /* n_fft > 8192, center == 0, n_mod_fft not a power of two ...    */
   MM_ERR_HIP = -3,          /* a HIP runtime call failed (see mm_last_hip_error)              */
   MM_ERR_WORKSPACE = -4,    /* workspace smaller than mm_workspace_bytes()                    */
   MM_ERR_ALLOC = -5
@@ -65,7 +65,7 @@ typedef enum mm_status {
  * plus the build's extensions (n_mels, preemph, top_db, amin, n_mod_fft). */
 typedef struct mm_config {
   double sr;          /* sample rate in Hz (sigSr)                                            */
-  int32_t n_fft;      /* FFT length, power of two, 32..4096                                   */
+  int32_t n_fft;      /* FFT length: ANY integer 2..8192 (librosa: any n_fft >= win_length)   */
   int32_t win_length; /* int(winLen*sigSr), 1..n_fft                                          */
   int32_t hop_length; /* int(tStep*sigSr), >= 1                                               */
   int32_t n_mels;     /* librosa default 128; 1..256                                          */
@@ -133,7 +133,10 @@ int mm_plan_config(const mm_plan* plan, mm_config* out);
  * pre-emphasis); 5 = 12-wave kernel with the mel contraction (and for n_mfcc <= 16 the DCT-II) on the
  * matrix pipe, 48-frame double-buffered power tiles (n_fft 512, hop <= 170 at 40 mel: the tables must fit
  * the 160 KB of LDS) -- opt-in (mm_plan_set_variant): measured slower than variant 4, see DESIGN.md.  n_fft 64 / 128 / 256 plans use the n_fft 512
- * variants too (frames zero-padded to 512 points: same power at every (512/n_fft)-th bin). */
+ * variants too (frames zero-padded to 512 points: same power at every (512/n_fft)-th bin).  6 = the any-length
+ * kernel: every n_fft that is not a power of two in [32, 4096] -- 400, 600, 1000, 1536, a prime, 8192, 16 -- as a
+ * mixed-radix (2 / 3 / 5 / 7) Stockham FFT in LDS, Bluestein's chirp-z transform for lengths with other prime factors
+ * (such a plan has this one kernel: variants and force_generic do not apply). */
 int mm_plan_kernel_path(const mm_plan* plan);
 /* 1 if mm_mfcc_f32 of this plan applies the DCT-II inside the log-mel kernel (variants 4 and 5: the DCT
  * of the unclamped rows, followed by a fix-up launch that redoes only the clips whose minimum lies more

@@ -145,7 +145,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError when the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.mm_version() < 114:
+    if lib.mm_version() < 120:
         raise ImportError("libmodmfcc.so is older than the Python binding; rebuild it")
     _lib = lib
     return lib

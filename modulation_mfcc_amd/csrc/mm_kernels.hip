@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_logmel12m.hip.inc"
 #include "mm_wpf.hip.inc"
 #include "mm_hilbert.hip.inc"
+#include "mm_anyfft.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 // plan
@@ -344,6 +345,7 @@ struct mm_plan {
   int k2_ok, wpf_r, wpf_waves, wpf_group_max;
   size_t wpf_lds_bytes;
   int num_cus;
+  AnyPlan any;                             // any-length STFT (mm_anyfft.hip.inc): n_fft that is not a power of two in [32, 4096]
   // timing
   int timing_on;
   std::vector<hipEvent_t> ev_pool;  // pairs
@@ -569,6 +571,10 @@ static std::vector<float> wpf_lane_table(int R, const float* win, const float* t
   return lt;
 }
 
+// n_fft the power-of-two kernels (radix-16 register kernels, stft_generic_kernel) take; everything else in [2, 8192]
+// runs on stft_any_kernel
+static bool nfft_is_pow2_class(int n) { return n >= 32 && n <= 4096 && (n & (n - 1)) == 0; }
+
 int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   if (!out) return MM_ERR_INVALID_ARG;
   *out = nullptr;
@@ -578,7 +584,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   if (!p) return MM_ERR_ALLOC;
   p->cfg = *cfg;
   p->n_bins = cfg->n_fft / 2 + 1;
-  p->log2nc = ilog2(cfg->n_fft) - 1;
+  p->log2nc = nfft_is_pow2_class(cfg->n_fft) ? ilog2(cfg->n_fft) - 1 : 0;
   p->kp = (cfg->n_mfcc + MM_DCT_KB - 1) / MM_DCT_KB * MM_DCT_KB;
   p->db_offset = 10.0f * log10f(fmaxf(cfg->amin, 1.0f));
   p->path = 0;
@@ -629,6 +635,30 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0)
       p->num_cus = prop.multiProcessorCount;
+  }
+  if (!nfft_is_pow2_class(cfg->n_fft)) {
+    // any other length: mixed-radix / Bluestein STFT in LDS (mm_anyfft.hip.inc); the only kernel of such a plan
+    std::vector<float> atw, asplit, achirp, abhat;
+    if (!any_plan_host(cfg->n_fft, &p->any, &atw, &asplit, &achirp, &abhat, MM_LM_LDS_MAX)) {
+      mm_plan_destroy(p);
+      return MM_ERR_UNSUPPORTED;
+    }
+    if ((rc = upload(&p->any.d_tw, atw.data(), std::max<size_t>(atw.size(), 2) * 4)) ||
+        (!asplit.empty() && (rc = upload(&p->any.d_split, asplit.data(), asplit.size() * 4))) ||
+        (!achirp.empty() && (rc = upload(&p->any.d_chirp, achirp.data(), achirp.size() * 4))) ||
+        (!abhat.empty() && (rc = upload(&p->any.d_bhat, abhat.data(), abhat.size() * 4)))) {
+      mm_plan_destroy(p);
+      return rc;
+    }
+    const void* kfn[4] = {(const void*)stft_any_kernel<0, 64>, (const void*)stft_any_kernel<1, 64>,
+                          (const void*)stft_any_kernel<0, 256>, (const void*)stft_any_kernel<1, 256>};
+    for (int i = 0; i < 4; ++i)
+      if (hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) {
+        g_hip_err = "hipFuncSetAttribute(stft_any_kernel) failed";
+        mm_plan_destroy(p);
+        return MM_ERR_HIP;
+      }
+    p->any.ok = true;       // (the n_fft-specific set-up below does not apply; the trajectory rFFT set-up at the end does)
   }
   // n_fft 64 / 128 / 256 ride on the n_fft = 512 tile kernels: a frame zero-padded to 512 points around
   // its centre has X512[E*k] = (-1)^k X_nfft[k] (E = 512 / n_fft), i.e. the same power at every E-th
@@ -928,6 +958,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_m12_a); (void)hipFree(p->d_m12_dct); (void)hipFree(p->d_zeros);
   (void)hipFree(p->d_dctfm_a);
   (void)hipFree(p->d_s16f_tab); (void)hipFree(p->d_s16f_dcta); (void)hipFree(p->d_s16f_part);
+  (void)hipFree(p->any.d_tw); (void)hipFree(p->any.d_split); (void)hipFree(p->any.d_chirp); (void)hipFree(p->any.d_bhat);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
   return MM_OK;
@@ -942,8 +973,9 @@ int mm_plan_config(const mm_plan* p, mm_config* out) {
 // Which fused kernel a log-mel / MFCC call runs on (mode 1; mode 0 = the power stage output).  `call`
 // = false answers for a regular call (aligned rows, n_samples >= 4).  p->variant (mm_plan_set_variant)
 // pins a variant where it applies; what a variant cannot take falls through to the next one.
-enum { MM_K_GENERIC = 0, MM_K_W8 = 1, MM_K_W16 = 2, MM_K_WPF = 3, MM_K_W16S = 4, MM_K_M12 = 5 };
+enum { MM_K_GENERIC = 0, MM_K_W8 = 1, MM_K_W16 = 2, MM_K_WPF = 3, MM_K_W16S = 4, MM_K_M12 = 5, MM_K_ANY = 6 };
 static int choose_kernel(const mm_plan* p, int mode, bool call, const float* d_audio, int64_t n_samples, int64_t stride) {
+  if (p->any.ok) return MM_K_ANY;
   if (p->force_generic) return MM_K_GENERIC;
   const int v = p->variant;
   const bool force_wpf = v == MM_K_WPF;
@@ -989,7 +1021,7 @@ int mm_plan_set_fuse_tail(mm_plan* p, int on) {
 }
 
 int mm_plan_set_variant(mm_plan* p, int variant) {
-  if (!p || variant < 0 || variant > MM_K_M12) return MM_ERR_INVALID_ARG;
+  if (!p || variant < 0 || variant > MM_K_M12) return MM_ERR_INVALID_ARG;      // (MM_K_ANY is not a choice: such plans have one kernel)
   const int prev = p->variant;
   p->variant = variant;
   return prev;
@@ -1041,6 +1073,32 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
                        int64_t stride, StftOut& o, hipStream_t st) {
   o.is_fm = false; o.fused_dct = false;
   const int kern = choose_kernel(p, mode, true, d_audio, n_samples, stride);
+  if (kern == MM_K_ANY) {
+    const AnyPlan& ap = p->any;
+    AnyParams q;
+    q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
+    q.n_frames = mm_num_frames(&p->cfg, n_samples);
+    q.n_fft = p->cfg.n_fft; q.hop = p->cfg.hop_length; q.n_bins = p->n_bins; q.n_mels = p->cfg.n_mels;
+    q.preemph = p->cfg.preemph; q.amin = p->cfg.amin; q.db_offset = p->db_offset; q.window = p->d_window;
+    q.nn = ap.nn; q.packed = ap.packed; q.n_pass = ap.n_pass; std::memcpy(q.radix, ap.radix, sizeof(q.radix));
+    q.M = ap.M; q.log2M = ap.log2M; q.tw = ap.d_tw; q.split = ap.d_split; q.chirp = ap.d_chirp; q.bhat = ap.d_bhat;
+    q.mel_start = p->d_mel_start; q.mel_len = p->d_mel_len; q.mel_off = p->d_mel_off; q.mel_w = p->d_mel_w;
+    q.out_power = o.power; q.out_logmel = o.logmel; q.clip_key = o.key_max;
+    q.frames_per_group = 4; q.grp_bytes = ap.grp_bytes; q.b_off = ap.b_off; q.p_off = ap.p_off;
+    const int G = 256 / ap.tpf, fpb = G * q.frames_per_group;
+    const int64_t grid = batch * ((q.n_frames + fpb - 1) / fpb);
+    if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+    const size_t lds = (size_t)G * ap.grp_bytes;
+    if (ap.tpf == 64) {
+      if (mode == 0) hipLaunchKernelGGL((stft_any_kernel<0, 64>), dim3((unsigned)grid), dim3(256), lds, st, q);
+      else hipLaunchKernelGGL((stft_any_kernel<1, 64>), dim3((unsigned)grid), dim3(256), lds, st, q);
+    } else {
+      if (mode == 0) hipLaunchKernelGGL((stft_any_kernel<0, 256>), dim3((unsigned)grid), dim3(256), lds, st, q);
+      else hipLaunchKernelGGL((stft_any_kernel<1, 256>), dim3((unsigned)grid), dim3(256), lds, st, q);
+    }
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
   if (kern == MM_K_WPF) {
     WpfParams q;
     const int R = p->wpf_r, F = 4 / R;

@@ -20,7 +20,8 @@ static const double kPi = 3.14159265358979323846;
 int validate(const mm_config* c) {
   if (!c) return MM_ERR_INVALID_ARG;
   if (!(c->sr > 0.0)) return MM_ERR_INVALID_ARG;
-  if (c->n_fft < 32 || c->n_fft > 4096 || (c->n_fft & (c->n_fft - 1))) return MM_ERR_UNSUPPORTED;
+  if (c->n_fft < 2) return MM_ERR_INVALID_ARG;
+  if (c->n_fft > 8192) return MM_ERR_UNSUPPORTED;     // any integer up to 8192 (librosa: any n_fft >= win_length)
   if (c->win_length < 1 || c->win_length > c->n_fft) return MM_ERR_INVALID_ARG;
   if (c->hop_length < 1) return MM_ERR_INVALID_ARG;
   if (c->n_mels < 1 || c->n_mels > 256) return MM_ERR_INVALID_ARG;

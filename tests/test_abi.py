@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/modmfcc.h but not exported"
     assert set(syms) == set(_lib.PROTOTYPES), set(syms) ^ set(_lib.PROTOTYPES)
-    assert lib.mm_version() == 114
+    assert lib.mm_version() == 120
     assert lib.mm_strerror(-2) == b"unsupported configuration"
 
 
@@ -47,7 +47,7 @@ def test_config_struct_layout_and_defaults():
 
 
 @pytest.mark.parametrize("bad,exc", [
-    (dict(n_fft=500), NotImplementedError), (dict(n_fft=8192), NotImplementedError),
+    (dict(n_fft=16384), NotImplementedError), (dict(n_fft=1, win_length=1), ValueError),
     (dict(win_length=600), ValueError), (dict(hop_length=0), ValueError),
     (dict(n_mfcc=200), ValueError), (dict(fmax=50.0), ValueError), (dict(center=False), NotImplementedError),
     (dict(amin=0.0), ValueError), (dict(n_mod_fft=1000), NotImplementedError),
@@ -56,6 +56,15 @@ def test_config_struct_layout_and_defaults():
 def test_validate_rejects(bad, exc):
     with pytest.raises(exc):
         MfccConfig(**bad).validate()
+
+
+@pytest.mark.parametrize("n_fft", [400, 500, 600, 1000, 1536, 441, 251, 8192, 16, 2, 8191])
+def test_any_integer_n_fft_is_a_valid_configuration(n_fft):
+    """librosa takes any n_fft >= win_length and the reference's dialog lets the user type one
+    (script/config_dialog.py:141,610): every integer in [2, 8192] validates (the non-power-of-two lengths run on
+    the mixed-radix / Bluestein STFT kernel, csrc/mm_anyfft.hip.inc)."""
+    c = MfccConfig(n_fft=n_fft, win_length=min(250, n_fft), n_mels=min(128, max(1, n_fft // 4)), n_mfcc=1).validate()
+    assert c.n_bins == n_fft // 2 + 1
 
 
 def test_reference_call_truncation():
@@ -73,6 +82,9 @@ CFGS = [
     dict(sr=48000, n_fft=2048, win_length=1200, hop_length=480, n_mels=80, n_mfcc=40, fmin=100.0, fmax=10000.0),
     dict(sr=22050, n_fft=1024, win_length=551, hop_length=220, n_mels=64, n_mfcc=20, fmin=0.0, fmax=11025.0),
     dict(sr=8000, n_fft=256, win_length=255, hop_length=3, n_mels=23, n_mfcc=23, fmin=20.0, fmax=3900.0),
+    dict(sr=16000, n_fft=400, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0),
+    dict(sr=10000, n_fft=1000, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0),
+    dict(sr=44100, n_fft=441, win_length=441, hop_length=147, n_mels=30, n_mfcc=12, fmin=50.0, fmax=20000.0),
 ]
 
 

@@ -595,6 +595,115 @@ def test_fused_tail_matches_separate_launches(extra, n, batches, gpu):
         assert float(lm.min()) < float(mx[0]) - 80.0
 
 
+_ANY_NFFT = [
+    # (cfg, what)
+    (dict(sr=16000, n_fft=400, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "400 = 2^4 5^2 (window == n_fft)"),
+    (dict(sr=10000, n_fft=400, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "reference defaults, n_fft 400"),
+    (dict(sr=10000, n_fft=1000, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "reference defaults, n_fft 1000"),
+    (dict(sr=16000, n_fft=600, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "600 = 2^3 3 5^2"),
+    (dict(sr=22050, n_fft=1536, win_length=551, hop_length=220, n_mels=64, n_mfcc=20, fmin=0.0, fmax=11025.0), "1536 = 2^9 3"),
+    (dict(sr=44100, n_fft=441, win_length=441, hop_length=147, n_mels=30, n_mfcc=12, fmin=50.0, fmax=20000.0), "441 = 3^2 7^2, odd"),
+    (dict(sr=8000, n_fft=875, win_length=800, hop_length=100, n_mels=40, n_mfcc=13, fmin=20.0, fmax=4000.0, preemph=0.97), "875 = 5^3 7, odd, pre-emphasis"),
+    (dict(sr=16000, n_fft=502, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "502 = 2 x 251: Bluestein on 251 points"),
+    (dict(sr=16000, n_fft=499, win_length=400, hop_length=161, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "499 prime: Bluestein, odd hop"),
+    (dict(sr=16000, n_fft=8192, win_length=4000, hop_length=1000, n_mels=128, n_mfcc=40, fmin=0.0, fmax=8000.0), "8192: workgroup per frame"),
+    (dict(sr=48000, n_fft=6000, win_length=4800, hop_length=960, n_mels=80, n_mfcc=20, fmin=100.0, fmax=20000.0), "6000 = 2^4 3 5^3: workgroup per frame"),
+    (dict(sr=16000, n_fft=8190, win_length=800, hop_length=400, n_mels=64, n_mfcc=13, fmin=100.0, fmax=8000.0), "8190 = 2 x 4095 (13 | 4095): Bluestein, M 8192"),
+    (dict(sr=48000, n_fft=4099, win_length=2400, hop_length=480, n_mels=80, n_mfcc=40, fmin=100.0, fmax=10000.0, top_db=40.0), "4099 prime, odd: Bluestein, M 16384"),
+    (dict(sr=8000, n_fft=16, win_length=16, hop_length=4, n_mels=4, n_mfcc=3, fmin=0.0, fmax=4000.0), "16: below the radix kernels' range"),
+    (dict(sr=8000, n_fft=6, win_length=5, hop_length=2, n_mels=2, n_mfcc=2, fmin=0.0, fmax=4000.0), "6"),
+    (dict(sr=8000, n_fft=3, win_length=3, hop_length=1, n_mels=2, n_mfcc=1, fmin=0.0, fmax=4000.0), "3"),
+    (dict(sr=8000, n_fft=2, win_length=2, hop_length=1, n_mels=1, n_mfcc=1, fmin=0.0, fmax=4000.0), "2"),
+]
+
+
+@pytest.mark.parametrize("kw,what", _ANY_NFFT, ids=[f"nfft{c[0]['n_fft']}_{i}" for i, c in enumerate(_ANY_NFFT)])
+def test_any_integer_n_fft_matches_oracle(kw, what, gpu):
+    """librosa.feature.mfcc takes any n_fft >= win_length and the reference's dialog passes what the user types
+    (script/config_dialog.py:141,610 -> script/main.py:1049-1066 -> script/mfcc.py:387): every length that is not a
+    power of two in [32, 4096] runs on stft_any_kernel -- mixed-radix Stockham FFT in LDS for 2/3/5/7-smooth lengths
+    (even: packed into n/2 complex points; odd: n complex points), Bluestein's chirp-z transform otherwise, one wave or
+    one workgroup per frame -- against the oracle: MFCC on am / quiet-tail (the clamp bites) / noise clips of ragged
+    lengths, the power and log-mel stage outputs, and MFCC + modulation spectrum in one call."""
+    import warnings
+    plan = _plan(kw)
+    assert plan.kernel_path == "any-length" and not plan.fused_dct
+    n_fft, hop = kw["n_fft"], kw["hop_length"]
+    okw = dict(kw)
+    okw["top_db"] = kw.get("top_db", 80.0)
+    ocfg = O.OracleConfig(**okw)
+    rng = np.random.default_rng(n_fft)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                     # empty mel filters of the tiny lengths
+        for n in (int(rng.integers(max(2, n_fft // 2), n_fft)), 3 * n_fft + 5 * hop + 1, 20 * hop + n_fft):
+            clips = np.stack([O.synth_clip(7 + n_fft + i, n, kw["sr"], k) for i, k in enumerate(("am", "quiet_tail", "noise"))])
+            got = plan.mfcc(_dev(clips, gpu)).cpu().numpy()
+            for i in range(3):
+                want = O.mfcc(clips[i], ocfg)
+                assert got[i].shape == want.shape
+                mfcc_close(got[i], want, f"n_fft {n_fft} ({what}) n {n} clip {i}")
+        y = clips[0]
+        P = plan.stft_power(_dev(y, gpu)[None, :])[0].cpu().numpy()
+        Pw = O.stft_power(y, n_fft, hop, kw["win_length"], kw.get("preemph", 0.0))
+        assert P.shape == Pw.shape == (1 + n // hop, n_fft // 2 + 1)
+        # float32 transform vs the float64 one rounded once: noise relative to the frame's largest bin
+        assert np.abs(P - Pw).max() <= 2e-5 * Pw.max(), np.abs(P - Pw).max() / Pw.max()
+        lm, mx = plan.logmel(_dev(y, gpu)[None, :])
+        lw = O.logmel_unclamped(y, ocfg).T
+        assert np.abs(lm[0].cpu().numpy() - lw).max() <= 2e-2 and abs(float(mx[0]) - lw.max()) <= 1e-3
+        m2, s2 = plan.mfcc_modspec(_dev(clips, gpu))
+        assert not plan.fused_tail(3, n)
+        np.testing.assert_array_equal(m2.cpu().numpy(), got)
+        wm = O.modspec(got[0])
+        assert np.abs(s2[0].cpu().numpy() - wm).max() <= 1e-4 * max(np.abs(wm).max(), 1e-30)
+
+
+@pytest.mark.parametrize("idx", range(16))
+def test_random_any_length_configs_match_oracle(idx, gpu):
+    """Random n_fft in [8, 3000] that are NOT powers of two (smooth and Bluestein lengths as they come), random window /
+    hop / mel bank / clamp / pre-emphasis, two ragged clips each, against the oracle."""
+    import warnings
+    rng = np.random.default_rng(31000 + idx)
+    while True:
+        n_fft = int(rng.integers(8, 3001))
+        if n_fft & (n_fft - 1):
+            break
+    win = int(rng.integers(max(2, n_fft // 4), n_fft + 1))
+    hop = int(rng.integers(1, max(2, win)))
+    sr = int(rng.choice([8000, 10000, 16000, 22050, 44100, 48000]))
+    n_mels = int(rng.integers(2, max(3, min(129, n_fft // 2))))
+    n_mfcc = int(rng.integers(1, min(n_mels, 40) + 1))
+    kw = dict(sr=sr, n_fft=n_fft, win_length=win, hop_length=hop, n_mels=n_mels, n_mfcc=n_mfcc,
+              fmin=float(rng.choice([0.0, 20.0, 100.0])), fmax=float(rng.choice([sr / 2, sr * 0.45, sr * 0.7])),
+              top_db=float(rng.choice([80.0, 40.0, -1.0])), preemph=float(rng.choice([0.0, 0.0, 0.97])))
+    plan = _plan(kw)
+    assert plan.kernel_path == "any-length"
+    okw = dict(kw, top_db=None if kw["top_db"] < 0 else kw["top_db"])
+    n = int(rng.integers(n_fft // 2, 6 * n_fft + 7 * hop))
+    clips = np.stack([O.synth_clip(900 + idx, n, sr, k) for k in ("am", "quiet_tail")])
+    got = plan.mfcc(_dev(clips, gpu)).cpu().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(2):
+            want = O.mfcc(clips[i], O.OracleConfig(**okw))
+            assert got[i].shape == want.shape
+            mfcc_close(got[i], want, f"any-length cfg {idx} {kw} clip {i}")
+
+
+def test_drop_in_with_a_typed_n_fft(gpu):
+    """get_MFCCS_change as the config dialog calls it (script/main.py:1049-1066) with n_fft values a user types --
+    400, 1000 -- at the UI's 10 kHz defaults: no NotImplementedError, results equal the oracle's."""
+    from modulation_mfcc_amd import get_MFCCS_change
+    kw, y, _ = load_golden("refdefault_am")
+    for n_fft in (400, 1000, 600):
+        tot, T = get_MFCCS_change(y, 10000, tStep=0.005, winLen=0.025, n_mfcc=13, n_fft=n_fft, removeFirst=1, filtCutoff=12,
+                                  filtOrd=6, diffMethod="grad", outFilter="iir", outFiltCutOff=[12])
+        wt, wT = O.get_MFCCS_change(y, 10000, tStep=0.005, winLen=0.025, n_mfcc=13, n_fft=n_fft, removeFirst=1, filtCutoff=12,
+                                    filtOrd=6, diffMethod="grad", outFilter="iir", outFiltCutOff=[12])
+        np.testing.assert_array_equal(T, wT)
+        assert np.abs(tot - wt).max() <= 1e-4 * np.abs(wt).max()
+
+
 def test_headline_config_through_the_headline_entry_point(gpu):
     """BASELINE configs[2] EXACTLY as bench.py times it: 1024 clips x 160 000 samples through mm_mfcc_modspec_f32
     in clip mode (ONE launch, 4 clips per workgroup, T 1001, n_mod 1024) -- the bench's signal model
