@@ -100,7 +100,7 @@ const char* mm_last_hip_error(void);
 /* ---- host-only helpers (no GPU needed) ------------------------------------------------ */
 int mm_config_default(mm_config* cfg);                           /* reference defaults      */
 int mm_config_validate(const mm_config* cfg);
-int64_t mm_num_frames(const mm_config* cfg, int64_t n_samples);  /* 1 + n_samples / hop     */
+int64_t mm_num_frames(const mm_config* cfg, int64_t n_samples);  /* 1 + (n_samples + 2 (n_fft / 2) - n_fft) / hop: 1 + n_samples / hop for even n_fft */
 int32_t mm_num_bins(const mm_config* cfg);                       /* n_fft/2 + 1             */
 int32_t mm_mod_fft_len(const mm_config* cfg, int64_t n_frames);  /* resolved n_mod_fft      */
 int mm_build_window(const mm_config* cfg, float* out /*[n_fft]*/);

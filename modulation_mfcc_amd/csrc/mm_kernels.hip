@@ -438,7 +438,10 @@ int mm_config_validate(const mm_config* c) { return mm::validate(c); }
 
 int64_t mm_num_frames(const mm_config* c, int64_t n_samples) {
   if (!c || c->hop_length < 1 || n_samples < 0) return MM_ERR_INVALID_ARG;
-  return 1 + n_samples / c->hop_length;
+  // librosa pads n_fft // 2 samples on both sides and keeps 1 + (padded - n_fft) // hop frames: an ODD n_fft pads
+  // one sample less than it consumes
+  const int64_t padded = n_samples + 2 * (int64_t)(c->n_fft / 2);
+  return padded < c->n_fft ? 0 : 1 + (padded - c->n_fft) / c->hop_length;
 }
 
 int32_t mm_num_bins(const mm_config* c) { return c ? c->n_fft / 2 + 1 : MM_ERR_INVALID_ARG; }

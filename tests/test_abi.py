@@ -65,6 +65,10 @@ def test_any_integer_n_fft_is_a_valid_configuration(n_fft):
     the mixed-radix / Bluestein STFT kernel, csrc/mm_anyfft.hip.inc)."""
     c = MfccConfig(n_fft=n_fft, win_length=min(250, n_fft), n_mels=min(128, max(1, n_fft // 4)), n_mfcc=1).validate()
     assert c.n_bins == n_fft // 2 + 1
+    # librosa: pad n_fft // 2 on both sides, 1 + (padded - n_fft) // hop frames -- one frame less at a hop boundary
+    # when n_fft is odd (the oracle's frame_signal does the same)
+    for n in (50, 99, 100, 101, 1000):
+        assert c.num_frames(n) == 1 + (n + 2 * (n_fft // 2) - n_fft) // c.hop_length == O.frame_signal(np.zeros(n, np.float32), n_fft, c.hop_length).shape[0]
 
 
 def test_reference_call_truncation():
