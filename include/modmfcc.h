@@ -278,6 +278,18 @@ int mm_pcm_decode_f32(const void* d_raw, int32_t fmt, int32_t channels, int64_t 
 int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_taps,
                     int32_t L, int32_t M, int32_t taps_per_phase, int64_t half_len, float* d_y, int64_t n_out,
                     void* stream);
+/* mm_resample_banded_f32: the same conversion as a banded GEMM on the matrix pipe (v_mfma_f32_16x16x4_f32: exact float32
+ *   products, float32 accumulation in tap order; within ~1e-6 of the float64 accumulation of mm_resample_f32) -- the
+ *   default of audio_io.resample_batch.  Outputs m = q F + 16 b + r (F = lcm(L, 16): a period of outputs with the same
+ *   taps; b < NB = F / 16; r < 16) read the window x[q S + lo_min + lo_off[b] + k], S = F M / L, k < 4 ksteps, through
+ *   d_atab [NB][ksteps / 4][64][4] (16-byte aligned; ksteps a multiple of 8): entry (b, ks / 4, lane, ks % 4) = the tap
+ *   of row r = lane % 16 at k = 4 ks + lane / 16 (zero outside the row's taps_per_phase taps); win = max_b lo_off[b] +
+ *   4 ksteps.  The host builds both tables
+ *   (audio_io.banded_tables).  Returns MM_ERR_UNSUPPORTED when one tile of 16 periods does not fit the LDS
+ *   (S + win > ~40 k samples): use mm_resample_f32 then. */
+int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_atab,
+                           const int32_t* d_lo_off, int32_t F, int32_t S, int32_t NB, int32_t ksteps, int32_t lo_min,
+                           int32_t win, float* d_y, int64_t n_out, void* stream);
 
 /* Measurement aid: float4 grid-stride device-to-device copy of n_floats (a multiple of 4; 16-byte
  * aligned pointers) on `stream` -- the practical HBM ceiling bench.py quotes beside the stage-isolated

@@ -115,6 +115,8 @@ PROTOTYPES = {
     "mm_hilbert_envelope": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.c_size_t, _vp]),
     "mm_pcm_decode_f32": (C.c_int, [_vp, C.c_int32, C.c_int32, _i64, _vp, _i64, _vp]),
     "mm_resample_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, _i64, _vp, _i64, _vp]),
+    "mm_resample_banded_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, _vp, _i64, _vp]),
     "mm_devcopy_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mm_timing_enable": (C.c_int, [_vp, C.c_int]),
     "mm_timing_read": (C.c_int, [_vp, _vp, _vp]),

@@ -22,7 +22,7 @@ from fractions import Fraction
 
 import numpy as np
 
-__all__ = ["read_wav_header", "load_wav", "load_audio", "design_taps", "resample_batch", "resample_ratio"]
+__all__ = ["read_wav_header", "load_wav", "load_audio", "design_taps", "resample_batch", "resample_ratio", "banded_tables"]
 
 _FMT = {("int", 8): 1, ("int", 16): 2, ("int", 24): 3, ("int", 32): 4, ("float", 32): 5, ("float", 64): 6}
 
@@ -156,13 +156,94 @@ def _device_taps(L, M, dev):
     return _TAPS[key]
 
 
-def resample_batch(x, sr_in: float, sr_out: float):
+def banded_tables(L: int, M: int, h: np.ndarray, half: int):
+    """The polyphase FIR as the banded GEMM mm_resample_banded_f32 runs on the matrix pipe (csrc/mm_resample.hip.inc).
+
+    Output m = q F + 16 b + r (F = lcm(L, 16): outputs F apart share their taps; b < NB = F / 16; r < 16) is
+    sum_k A[b][r][k] x[q S + lo_b + k] with S = F M / L.  With t = u M + half, ih0(u) = t div L, ph0(u) = t mod L for
+    u = 16 b + r:  lo_b = ih0(16 b) - tpp + 1  and  A[b][r][k] = h[ph0(u) + (ih0(u) - lo_b - k) L]  (zero where the tap
+    index falls outside the filter).  Returns dict(atab float32 [NB, ksteps / 4, 64, 4] in MFMA lane order -- lane l of
+    k-step ks holds row r = l % 16 at k = 4 ks + l // 16; entry [b][ks // 4][l][ks % 4] --, lo_off int32 [NB], F, S, NB,
+    ksteps (a multiple of 8), lo_min, win)."""
+    L, M, half = int(L), int(M), int(half)
+    F = L * 16 // math.gcd(L, 16)
+    S = F * M // L
+    NB = F // 16
+    tpp = -(-len(h) // L)
+    u = np.arange(F, dtype=np.int64)
+    t = u * M + half
+    ih0, ph0 = t // L, t % L
+    lo = ih0[0::16] - tpp + 1                                  # [NB]
+    hi = ih0[15::16]
+    K = int((hi - lo + 1).max())
+    ksteps = -(-K // 32) * 8                                   # k-steps of 4 samples, in groups of 8 (the kernel's pipeline unit)
+    k = np.arange(4 * ksteps, dtype=np.int64)
+    hp = np.concatenate([np.asarray(h, dtype=np.float64), np.zeros(L)])
+    A = np.zeros((NB, 16, 4 * ksteps), dtype=np.float32)
+    for b in range(NB):
+        uu = 16 * b + np.arange(16)
+        j = ih0[uu][:, None] - lo[b] - k[None, :]              # [16, K]
+        idx = ph0[uu][:, None] + j * L
+        ok = (j >= 0) & (idx < len(h))
+        A[b] = np.where(ok, hp[np.clip(idx, 0, len(hp) - 1)], 0.0).astype(np.float32)
+    # MFMA A-operand order: step ks, lane l = 16 kq + r  <-  A[b][r][4 ks + kq]; stored [b][ks / 4][lane][ks % 4] so that
+    # a lane fetches its taps of four consecutive k-steps with one 16-byte load
+    steps = A.reshape(NB, 16, ksteps, 4).transpose(0, 2, 3, 1).reshape(NB, ksteps, 64)        # [b][ks][lane]
+    atab = np.ascontiguousarray(steps.reshape(NB, ksteps // 4, 4, 64).transpose(0, 1, 3, 2))     # [b][ks / 4][lane][4]
+    lo_off = (lo - lo[0]).astype(np.int32)
+    return dict(atab=atab, lo_off=lo_off, F=F, S=S, NB=NB, ksteps=ksteps, lo_min=int(lo[0]),
+                win=int(lo_off.max()) + 4 * ksteps, A=A, lo=lo)
+
+
+def banded_resample_numpy(x, tabs, n_out):
+    """NumPy statement of what the kernel computes from banded_tables() (host logic, tests): float64 accumulation."""
+    x = np.asarray(x, dtype=np.float64)
+    F, S, NB = tabs["F"], tabs["S"], tabs["NB"]
+    A, lo = tabs["A"].astype(np.float64), tabs["lo"]
+    K = A.shape[2]
+    periods = -(-n_out // F)
+    pad_l = max(0, -int(lo.min()))
+    xp = np.concatenate([np.zeros(pad_l), x, np.zeros(periods * S + int(lo.max()) + K + 1)])
+    y = np.zeros(periods * F)
+    for q in range(periods):
+        for b in range(NB):
+            w = xp[pad_l + q * S + int(lo[b]): pad_l + q * S + int(lo[b]) + K]
+            y[q * F + 16 * b: q * F + 16 * b + 16] = A[b] @ w
+    return y[:n_out]
+
+
+_BANDED = collections.OrderedDict()
+
+
+def _device_banded(L, M, dev):
+    import torch
+    key = (L, M, str(dev))
+    if key in _BANDED:
+        _BANDED.move_to_end(key)
+    else:
+        while len(_BANDED) >= TAPS_MAX:
+            torch.cuda.synchronize(dev)
+            _BANDED.popitem(last=False)
+        h, half = design_taps(L, M)
+        tb = banded_tables(L, M, h.astype(np.float32).astype(np.float64), half)     # the float32 taps both kernels use
+        _BANDED[key] = dict(tb, d_atab=torch.from_numpy(tb["atab"]).to(dev), d_lo_off=torch.from_numpy(tb["lo_off"]).to(dev))
+        del _BANDED[key]["A"], _BANDED[key]["atab"]
+    return _BANDED[key]
+
+
+def resample_batch(x, sr_in: float, sr_out: float, method: str = "auto"):
     """Sample-rate conversion along the last axis of a float32 CUDA(HIP) tensor ([n] or [rows, n]) on the
-    device: ceil(n * sr_out / sr_in) samples per row, zero phase (librosa.resample's length and alignment)."""
+    device: ceil(n * sr_out / sr_in) samples per row, zero phase (librosa.resample's length and alignment).
+
+    method 'auto' / 'mfma': the banded GEMM on the matrix pipe (mm_resample_banded_f32: float32 accumulation in tap
+    order, ~1e-6 of full scale from the float64 sum); 'f64': the vector-pipe kernel with float64 accumulation
+    (mm_resample_f32; also the fall-back for ratios whose period does not fit the LDS tile)."""
     import torch
     from . import _lib
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
         raise TypeError("x must be a float32 CUDA(HIP) tensor")
+    if method not in ("auto", "mfma", "f64"):
+        raise ValueError("method must be 'auto', 'mfma' or 'f64'")
     L, M = resample_ratio(sr_in, sr_out)
     if L == M:
         return x.clone()
@@ -174,14 +255,27 @@ def resample_batch(x, sr_in: float, sr_out: float):
         x2 = x2.contiguous()
     rows, n = x2.shape
     n_out = -(-n * L // M)
-    taps, tpp, half = _device_taps(L, M, x.device)
     out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    with torch.cuda.device(x.device):
-        for r0 in range(0, rows, 65535):         # the kernel's grid takes the rows on its y axis
-            r = min(65535, rows - r0)
-            _lib.check(lib.mm_resample_f32(x2[r0:].data_ptr(), r, n, x2.stride(0), taps.data_ptr(), L, M, tpp, half,
-                                           out[r0:].data_ptr(), n_out, _stream(torch, x.device)), "mm_resample_f32")
+    done = False
+    if method != "f64" and L * 16 // math.gcd(L, 16) * M // L <= 65536:
+        tb = _device_banded(L, M, x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.mm_resample_banded_f32(x2.data_ptr(), rows, n, x2.stride(0), tb["d_atab"].data_ptr(), tb["d_lo_off"].data_ptr(),
+                                            tb["F"], tb["S"], tb["NB"], tb["ksteps"], tb["lo_min"], tb["win"], out.data_ptr(),
+                                            n_out, _stream(torch, x.device))
+        if rc == _lib.MM_ERR_UNSUPPORTED and method == "auto":
+            done = False
+        else:
+            _lib.check(rc, "mm_resample_banded_f32")
+            done = True
+    if not done:
+        taps, tpp, half = _device_taps(L, M, x.device)
+        with torch.cuda.device(x.device):
+            for r0 in range(0, rows, 65535):         # the kernel's grid takes the rows on its y axis
+                r = min(65535, rows - r0)
+                _lib.check(lib.mm_resample_f32(x2[r0:].data_ptr(), r, n, x2.stride(0), taps.data_ptr(), L, M, tpp, half,
+                                               out[r0:].data_ptr(), n_out, _stream(torch, x.device)), "mm_resample_f32")
     return out[0] if squeeze else out
 
 

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_wpf.hip.inc"
 #include "mm_hilbert.hip.inc"
 #include "mm_anyfft.hip.inc"
+#include "mm_resample.hip.inc"
 
 // ------------------------------------------------------------------------------------------
 // plan
@@ -1797,6 +1798,61 @@ int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stri
   if ((F + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, d_x,
                      n_in, x_stride, d_taps, L, M, taps_per_phase / 4, half_len, n_out, F, d_y);
+  HIP_TRY(hipGetLastError());
+  return MM_OK;
+}
+
+// The same conversion as a banded GEMM on the matrix pipe (mm_resample.hip.inc).  The host lays the taps out as MFMA A
+// operands (modulation_mfcc_amd/audio_io.py: banded_tables): d_atab [NB][ksteps][64] floats, d_lo_off [NB] int32;
+// F = lcm(L, 16) outputs per period, S = F M / L input samples per period, lo_min = first input sample (relative to a
+// period's origin, may be negative) of the first block's window, win = floats of one period's window union.
+int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_atab,
+                           const int32_t* d_lo_off, int32_t F, int32_t S, int32_t NB, int32_t ksteps, int32_t lo_min,
+                           int32_t win, float* d_y, int64_t n_out, void* stream) {
+  if (!d_x || !d_atab || !d_lo_off || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || F < 16 || (F & 15) || S < 1 ||
+      NB != F / 16 || ksteps < 8 || (ksteps & 7) || win < 4 * ksteps || n_out < 1 || (((uintptr_t)d_atab) & 15))
+    return MM_ERR_INVALID_ARG;
+  // bank pattern of one ds_read_b32: lanes (k = 0, 1) x (q = 0 .. 15) read words q S + k -- pad the tile when more than
+  // two of them share a bank
+  int cnt[32] = {0}, worst = 0;
+  for (int k = 0; k < 2; ++k)
+    for (int q = 0; q < 16; ++q) worst = std::max(worst, ++cnt[(int)(((int64_t)q * S + k) & 31)]);
+  const bool pad = worst > 2;
+  auto tile_bytes = [&](int qt) {
+    const int64_t fl = (int64_t)(16 * qt - 1) * S + win;
+    return (size_t)(pad ? fl + (fl >> 5) + 1 : fl) * 4;
+  };
+  // periods per tile = 16 QT: the largest tile of which two fit a CU (two workgroups: one stages while the other
+  // multiplies) -- ratios with few blocks per period (1 / 3: NB = 1) get their units from more period tiles
+  int QT = 8;
+  while (QT > 1 && tile_bytes(QT) > 80 * 1024) QT >>= 1;
+  if (tile_bytes(QT) > MM_LM_LDS_MAX) return MM_ERR_UNSUPPORTED;     // (the caller falls back to mm_resample_f32)
+  RsmParams q;
+  q.x = d_x; q.rows = rows; q.n_in = n_in; q.x_stride = x_stride; q.atab = d_atab; q.lo_off = d_lo_off;
+  q.F = F; q.S = S; q.NB = NB; q.ksteps = ksteps; q.lo_min = lo_min; q.QT = QT;
+  q.tile_floats = (int)((int64_t)(16 * QT - 1) * S + win);
+  q.y = d_y; q.n_out = n_out;
+  const int64_t periods = (n_out + F - 1) / F;
+  q.tiles_per_row = (periods + 16 * QT - 1) / (16 * QT);
+  q.n_items = rows * q.tiles_per_row;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)resample_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)resample_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) {
+      g_hip_err = "hipFuncSetAttribute(resample_mfma_kernel) failed";
+      return MM_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const size_t lds = tile_bytes(QT);
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (size_t)MM_LM_LDS_MAX / lds));
+  const int64_t grid = std::min<int64_t>(q.n_items, (int64_t)per_cu * cus);
+  if (pad) hipLaunchKernelGGL(resample_mfma_kernel<true>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, q);
+  else hipLaunchKernelGGL(resample_mfma_kernel<false>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, q);
   HIP_TRY(hipGetLastError());
   return MM_OK;
 }

@@ -1276,18 +1276,25 @@ def test_load_and_resample_on_device(tmp_path, gpu):
             if not ext and not (kind == "int" and bits == 24):
                 _, ref = scipy.io.wavfile.read(p)           # same samples as an independent reader sees
                 assert ref.reshape(30001, -1).shape[1] == ch
-    # resampler kernel == upfirdn with the same taps (float64 accumulation on both sides)
+    # resampler kernels == upfirdn with the same taps.  'f64' (vector pipe, float64 accumulation like scipy): 2e-6 of the
+    # maximum, i.e. the float32 rounding of the result; 'mfma' (the default: banded GEMM on the matrix pipe, exact float32
+    # products, float32 accumulation in two tap-ordered fmaf chains of ~taps / 2 terms): the accumulation adds
+    # ~1e-7 sqrt(280) of the sum's magnitude -- bound 6e-6 of the maximum, -104 dB, far under the filter's own 1e-5
+    # pass-band ripple and three orders under what the MFCC tolerance needs (a 1e-5 sample error moves a log-mel value
+    # by < 1e-4 dB)
     xs = rng.standard_normal((3, 20000)).astype(np.float32)
-    for sr_in, sr_out in ((48000, 16000), (44100, 16000), (44100, 10000), (16000, 10000), (8000, 16000), (16000, 16000)):
-        got = resample_batch(_dev(xs, gpu), sr_in, sr_out).cpu().numpy()
+    TOL = {"f64": 2e-6, "auto": 6e-6}        # 'auto' = the matrix-pipe kernel wherever one period fits its LDS tile
+    for sr_in, sr_out in ((48000, 16000), (44100, 16000), (44100, 10000), (16000, 10000), (8000, 16000), (22050, 16000), (16000, 16000)):
         L, M = resample_ratio(sr_in, sr_out)
         if L == M:
-            np.testing.assert_array_equal(got, xs)
+            np.testing.assert_array_equal(resample_batch(_dev(xs, gpu), sr_in, sr_out).cpu().numpy(), xs)
             continue
         h, half = design_taps(L, M)
         want = scipy.signal.resample_poly(xs.astype(np.float64), L, M, axis=1, window=h.astype(np.float32).astype(np.float64) / L)
-        assert got.shape == want.shape == (3, -(-20000 * L // M))
-        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+        for method in ("auto", "f64"):
+            got = resample_batch(_dev(xs, gpu), sr_in, sr_out, method=method).cpu().numpy()
+            assert got.shape == want.shape == (3, -(-20000 * L // M))
+            assert np.abs(got - want).max() <= TOL[method] * np.abs(want).max(), (sr_in, sr_out, method, np.abs(got - want).max() / np.abs(want).max())
     # clips shorter than the filter (every tap range is clipped at both ends), odd lengths, a single row, upsampling
     for n, sr_in, sr_out in ((1, 44100, 16000), (7, 44100, 16000), (300, 44100, 16000), (301, 48000, 16000), (999, 16000, 44100),
                              (4097, 22050, 16000), (50001, 44100, 16000)):
@@ -1295,11 +1302,17 @@ def test_load_and_resample_on_device(tmp_path, gpu):
         L, M = resample_ratio(sr_in, sr_out)
         h, half = design_taps(L, M)
         want = scipy.signal.resample_poly(xr.astype(np.float64), L, M, axis=1, window=h.astype(np.float32).astype(np.float64) / L)
-        got = resample_batch(_dev(xr, gpu), sr_in, sr_out).cpu().numpy()
-        assert got.shape == want.shape == (2, -(-n * L // M))
-        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-30), (n, sr_in, sr_out)
-        one = resample_batch(_dev(xr[1], gpu), sr_in, sr_out).cpu().numpy()
-        np.testing.assert_array_equal(one, got[1])
+        for method in ("auto", "f64"):
+            got = resample_batch(_dev(xr, gpu), sr_in, sr_out, method=method).cpu().numpy()
+            assert got.shape == want.shape == (2, -(-n * L // M))
+            assert np.abs(got - want).max() <= TOL[method] * max(np.abs(want).max(), 1e-30), (n, sr_in, sr_out, method)
+            one = resample_batch(_dev(xr[1], gpu), sr_in, sr_out, method=method).cpu().numpy()
+            np.testing.assert_array_equal(one, got[1])
+    # a batch of ten-second clips with unaligned row pitch (the 16-byte stores fall back to scalar ones), and rows > tile
+    xb = torch.randn((37, 441000 + 3), device=gpu)[:, :441000]
+    a_ = resample_batch(xb, 44100, 16000, method="mfma")
+    b_ = resample_batch(xb, 44100, 16000, method="f64")
+    assert a_.shape == b_.shape == (37, 160000) and float((a_ - b_).abs().max()) <= 6e-6 * float(b_.abs().max())
     # drop-in: a path at the file's own rate gives exactly what the array gives; a resampled path is close to it
     kw, y, exp = load_golden("refdefault_am")
     p = str(tmp_path / "clip.wav")

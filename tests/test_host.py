@@ -184,6 +184,42 @@ def test_resampler_quality(sr_in, sr_out):
         assert 20 * np.log10(np.abs(alias[mid]).max()) < -115.0
 
 
+@pytest.mark.parametrize("sr_in,sr_out", [(44100, 16000), (44100, 10000), (48000, 16000), (16000, 10000), (8000, 16000),
+                                          (22050, 16000), (16000, 44100)])
+def test_resampler_as_a_banded_gemm_on_the_host(sr_in, sr_out):
+    """Row N4, host part of the matrix-pipe resampler: audio_io.banded_tables lays the polyphase FIR out as the banded
+    GEMM mm_resample_banded_f32 multiplies (outputs m = q F + 16 b + r against the window x[q S + lo_b + k]); applied with
+    numpy (banded_resample_numpy: exactly the kernel's index arithmetic, float64 sums) it reproduces
+    scipy.signal.resample_poly with the same taps on clips shorter than the filter, ragged lengths and long clips;
+    the MFMA lane order of the A table is the documented one."""
+    from modulation_mfcc_amd.audio_io import banded_resample_numpy, banded_tables, design_taps, resample_ratio
+    L, M = resample_ratio(sr_in, sr_out)
+    h, half = design_taps(L, M)
+    h = h.astype(np.float32).astype(np.float64)
+    tb = banded_tables(L, M, h, half)
+    F, S, NB, ks = tb["F"], tb["S"], tb["NB"], tb["ksteps"]
+    assert F % 16 == 0 and F % L == 0 and S * L == F * M and NB == F // 16
+    assert ks % 8 == 0 and tb["atab"].shape == (NB, ks // 4, 64, 4) and tb["lo_off"].shape == (NB,) and tb["lo_off"][0] == 0
+    assert tb["win"] == int(tb["lo_off"].max()) + 4 * ks
+    for b in (0, NB - 1):                       # lane l of step s holds A[b][r = l % 16][k = 4 s + l // 16]
+        for s_ in (0, ks // 2, ks - 1):
+            for lane in (0, 17, 35, 63):
+                assert tb["atab"][b, s_ // 4, lane, s_ % 4] == tb["A"][b, lane % 16, 4 * s_ + lane // 16]
+    # every row of every block carries all of its phase's taps: row sums = the polyphase branches' DC gains
+    u = np.arange(F)
+    ph = (u * M + half) % L
+    want_dc = np.array([h[p_::L].sum() for p_ in ph])
+    np.testing.assert_allclose(tb["A"].astype(np.float64).sum(axis=2).reshape(-1), want_dc, rtol=0, atol=1e-5)
+    rng = np.random.default_rng(1)
+    for n in (1, 5, 333, 4001, 20000):
+        x = rng.standard_normal(n)
+        n_out = -(-n * L // M)
+        want = scipy.signal.resample_poly(x, L, M, window=h / L)
+        got = banded_resample_numpy(x, tb, n_out)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0) + 1e-13, (n, np.abs(got - want).max())
+
+
 def _stencil_numpy(st, y):
     n = len(y)
     out = np.empty(n)
