@@ -280,11 +280,11 @@ int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stri
                     void* stream);
 /* mm_resample_banded_f32: the same conversion as a banded GEMM on the matrix pipe (v_mfma_f32_16x16x4_f32: exact float32
  *   products, float32 accumulation in tap order; within ~1e-6 of the float64 accumulation of mm_resample_f32) -- the
- *   default of audio_io.resample_batch.  Outputs m = q F + 16 b + r (F = lcm(L, 16): a period of outputs with the same
- *   taps; b < NB = F / 16; r < 16) read the window x[q S + lo_min + lo_off[b] + k], S = F M / L, k < 4 ksteps, through
+ *   default of audio_io.resample_batch.  Outputs m = q F + 16 b + r (F >= 16 a multiple of L: a period of outputs with
+ *   the same taps; b < NB = ceil(F / 16); r < 16, 16 b + r < F) read the window x[q S + lo_min + lo_off[b] + k], S = F M / L, k < 4 ksteps, through
  *   d_atab [NB][ksteps / 4][64][4] (16-byte aligned; ksteps a multiple of 8): entry (b, ks / 4, lane, ks % 4) = the tap
- *   of row r = lane % 16 at k = 4 ks + lane / 16 (zero outside the row's taps_per_phase taps); win = max_b lo_off[b] +
- *   4 ksteps.  The host builds both tables
+ *   of row r = lane % 16 at window sample k = 32 (ks / 8) + KOFF[lane / 16] + ks % 8, KOFF = {0, 16, 8, 24} (zero
+ *   outside the row's taps_per_phase taps); win = max_b lo_off[b] + 4 ksteps.  The host builds both tables
  *   (audio_io.banded_tables).  Returns MM_ERR_UNSUPPORTED when one tile of 16 periods does not fit the LDS
  *   (S + win > ~40 k samples): use mm_resample_f32 then. */
 int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_atab,

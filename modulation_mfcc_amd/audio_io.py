@@ -156,21 +156,28 @@ def _device_taps(L, M, dev):
     return _TAPS[key]
 
 
+BANDED_KOFF = (0, 16, 8, 24)      # first sample (within a group of 32) of lane quarter kq: see banded_tables
+
+
 def banded_tables(L: int, M: int, h: np.ndarray, half: int):
     """The polyphase FIR as the banded GEMM mm_resample_banded_f32 runs on the matrix pipe (csrc/mm_resample.hip.inc).
 
-    Output m = q F + 16 b + r (F = lcm(L, 16): outputs F apart share their taps; b < NB = F / 16; r < 16) is
+    Output m = q F + 16 b + r (F a multiple of L: outputs F apart share their taps; b < NB = ceil(F / 16); r < 16,
+    16 b + r < F) is
     sum_k A[b][r][k] x[q S + lo_b + k] with S = F M / L.  With t = u M + half, ih0(u) = t div L, ph0(u) = t mod L for
     u = 16 b + r:  lo_b = ih0(16 b) - tpp + 1  and  A[b][r][k] = h[ph0(u) + (ih0(u) - lo_b - k) L]  (zero where the tap
     index falls outside the filter).  Returns dict(atab float32 [NB, ksteps / 4, 64, 4] in MFMA lane order -- lane l of
-    k-step ks holds row r = l % 16 at k = 4 ks + l // 16; entry [b][ks // 4][l][ks % 4] --, lo_off int32 [NB], F, S, NB,
-    ksteps (a multiple of 8), lo_min, win)."""
+    k-step ks = 8 g + s holds row r = l % 16 at k = 32 g + BANDED_KOFF[l // 16] + s; entry [b][ks // 4][l][ks % 4] --,
+    lo_off int32 [NB], F, S, NB, ksteps (a multiple of 8), lo_min, win)."""
     L, M, half = int(L), int(M), int(half)
-    F = L * 16 // math.gcd(L, 16)
+    # period F = c L outputs: the smallest multiple of L that is >= 16 and wastes at most 13 % of its last 16-row block
+    # (c = 16 / gcd(L, 16) wastes nothing; a short period keeps S, hence the LDS tile of 16 periods, small)
+    c = next(c for c in range(max(1, -(-16 // L)), 17) if (-(-(c * L) // 16) * 16) <= 1.13 * c * L)
+    F = c * L
     S = F * M // L
-    NB = F // 16
+    NB = -(-F // 16)
     tpp = -(-len(h) // L)
-    u = np.arange(F, dtype=np.int64)
+    u = np.arange(16 * NB, dtype=np.int64)                     # rows past F wrap into the next period: computed, not stored
     t = u * M + half
     ih0, ph0 = t // L, t % L
     lo = ih0[0::16] - tpp + 1                                  # [NB]
@@ -186,9 +193,15 @@ def banded_tables(L: int, M: int, h: np.ndarray, half: int):
         idx = ph0[uu][:, None] + j * L
         ok = (j >= 0) & (idx < len(h))
         A[b] = np.where(ok, hp[np.clip(idx, 0, len(hp) - 1)], 0.0).astype(np.float32)
-    # MFMA A-operand order: step ks, lane l = 16 kq + r  <-  A[b][r][4 ks + kq]; stored [b][ks / 4][lane][ks % 4] so that
-    # a lane fetches its taps of four consecutive k-steps with one 16-byte load
-    steps = A.reshape(NB, 16, ksteps, 4).transpose(0, 2, 3, 1).reshape(NB, ksteps, 64)        # [b][ks][lane]
+    # MFMA A-operand order.  The kernel's K order inside a group of 32 samples: lane quarter kq (lane l = 16 kq + r) owns
+    # the 8 consecutive samples KOFF[kq] + 0 .. 7, KOFF = 0 / 16 / 8 / 24 (bank-conflict-free LDS reads for odd S), i.e.
+    # k-step ks = 8 g + s multiplies x-window sample k = 32 g + KOFF[kq] + s.  Stored [b][ks / 4][lane][ks % 4]: a lane
+    # fetches its taps of four consecutive k-steps with one 16-byte load.
+    G = ksteps // 8
+    Ag = A.reshape(NB, 16, G, 4, 8)                            # [b][r][g][chunk of 8 = k // 8 % 4][s]
+    chunk_of_kq = np.array(BANDED_KOFF) // 8                   # kq -> chunk
+    steps = Ag[:, :, :, chunk_of_kq, :]                        # [b][r][g][kq][s]
+    steps = steps.transpose(0, 2, 4, 3, 1).reshape(NB, ksteps, 64)                               # [b][ks = 8 g + s][lane = 16 kq + r]
     atab = np.ascontiguousarray(steps.reshape(NB, ksteps // 4, 4, 64).transpose(0, 1, 3, 2))     # [b][ks / 4][lane][4]
     lo_off = (lo - lo[0]).astype(np.int32)
     return dict(atab=atab, lo_off=lo_off, F=F, S=S, NB=NB, ksteps=ksteps, lo_min=int(lo[0]),
@@ -208,7 +221,8 @@ def banded_resample_numpy(x, tabs, n_out):
     for q in range(periods):
         for b in range(NB):
             w = xp[pad_l + q * S + int(lo[b]): pad_l + q * S + int(lo[b]) + K]
-            y[q * F + 16 * b: q * F + 16 * b + 16] = A[b] @ w
+            nr = min(16, F - 16 * b)                   # rows past the period's F outputs are not stored
+            y[q * F + 16 * b: q * F + 16 * b + nr] = (A[b] @ w)[:nr]
     return y[:n_out]
 
 
@@ -258,7 +272,7 @@ def resample_batch(x, sr_in: float, sr_out: float, method: str = "auto"):
     out = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     done = False
-    if method != "f64" and L * 16 // math.gcd(L, 16) * M // L <= 65536:
+    if method != "f64":
         tb = _device_banded(L, M, x.device)
         with torch.cuda.device(x.device):
             rc = lib.mm_resample_banded_f32(x2.data_ptr(), rows, n, x2.stride(0), tb["d_atab"].data_ptr(), tb["d_lo_off"].data_ptr(),

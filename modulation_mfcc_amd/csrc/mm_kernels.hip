@@ -1809,8 +1809,8 @@ int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stri
 int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_atab,
                            const int32_t* d_lo_off, int32_t F, int32_t S, int32_t NB, int32_t ksteps, int32_t lo_min,
                            int32_t win, float* d_y, int64_t n_out, void* stream) {
-  if (!d_x || !d_atab || !d_lo_off || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || F < 16 || (F & 15) || S < 1 ||
-      NB != F / 16 || ksteps < 8 || (ksteps & 7) || win < 4 * ksteps || n_out < 1 || (((uintptr_t)d_atab) & 15))
+  if (!d_x || !d_atab || !d_lo_off || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || F < 16 || S < 1 ||
+      NB != (F + 15) / 16 || ksteps < 8 || (ksteps & 7) || win < 4 * ksteps || n_out < 1 || (((uintptr_t)d_atab) & 15))
     return MM_ERR_INVALID_ARG;
   // bank pattern of one ds_read_b32: lanes (k = 0, 1) x (q = 0 .. 15) read words q S + k -- pad the tile when more than
   // two of them share a bank
@@ -1819,13 +1819,19 @@ int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t
     for (int q = 0; q < 16; ++q) worst = std::max(worst, ++cnt[(int)(((int64_t)q * S + k) & 31)]);
   const bool pad = worst > 2;
   auto tile_bytes = [&](int qt) {
-    const int64_t fl = (int64_t)(16 * qt - 1) * S + win;
+    const int64_t fl = (int64_t)(16 * qt - 1) * S + win + 8;        // + the alignment shift and the last 16-byte vector
     return (size_t)(pad ? fl + (fl >> 5) + 1 : fl) * 4;
   };
   // periods per tile = 16 QT: the largest tile of which two fit a CU (two workgroups: one stages while the other
   // multiplies) -- ratios with few blocks per period (1 / 3: NB = 1) get their units from more period tiles
+#ifndef MM_RSM_TILE_KB
+#define MM_RSM_TILE_KB 80
+#endif
+#ifndef MM_RSM_WG_PER_CU
+#define MM_RSM_WG_PER_CU 4          // small tiles (1 / 3, 2 / 1 ...): four workgroups per CU, 0.76 -> 0.67 ms at 48 -> 16 kHz
+#endif
   int QT = 8;
-  while (QT > 1 && tile_bytes(QT) > 80 * 1024) QT >>= 1;
+  while (QT > 1 && tile_bytes(QT) > MM_RSM_TILE_KB * 1024) QT >>= 1;
   if (tile_bytes(QT) > MM_LM_LDS_MAX) return MM_ERR_UNSUPPORTED;     // (the caller falls back to mm_resample_f32)
   RsmParams q;
   q.x = d_x; q.rows = rows; q.n_in = n_in; q.x_stride = x_stride; q.atab = d_atab; q.lo_off = d_lo_off;
@@ -1837,11 +1843,13 @@ int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t
   q.n_items = rows * q.tiles_per_row;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)resample_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess ||
-        hipFuncSetAttribute((const void*)resample_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) {
-      g_hip_err = "hipFuncSetAttribute(resample_mfma_kernel) failed";
-      return MM_ERR_HIP;
-    }
+    const void* kf[4] = {(const void*)resample_mfma_kernel<false, false>, (const void*)resample_mfma_kernel<false, true>,
+                         (const void*)resample_mfma_kernel<true, false>, (const void*)resample_mfma_kernel<true, true>};
+    for (int i = 0; i < 4; ++i)
+      if (hipFuncSetAttribute(kf[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) {
+        g_hip_err = "hipFuncSetAttribute(resample_mfma_kernel) failed";
+        return MM_ERR_HIP;
+      }
     attr_done = true;
   }
   int dev = 0, cus = 256;
@@ -1849,10 +1857,13 @@ int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     cus = prop.multiProcessorCount;
   const size_t lds = tile_bytes(QT);
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (size_t)MM_LM_LDS_MAX / lds));
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(MM_RSM_WG_PER_CU, (size_t)MM_LM_LDS_MAX / lds));
   const int64_t grid = std::min<int64_t>(q.n_items, (int64_t)per_cu * cus);
-  if (pad) hipLaunchKernelGGL(resample_mfma_kernel<true>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, q);
-  else hipLaunchKernelGGL(resample_mfma_kernel<false>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, q);
+  const bool vec = (((uintptr_t)d_x) & 15) == 0 && (x_stride & 3) == 0;
+  const dim3 gd((unsigned)grid), bd(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (pad) { if (vec) hipLaunchKernelGGL((resample_mfma_kernel<true, true>), gd, bd, lds, st, q); else hipLaunchKernelGGL((resample_mfma_kernel<true, false>), gd, bd, lds, st, q); }
+  else { if (vec) hipLaunchKernelGGL((resample_mfma_kernel<false, true>), gd, bd, lds, st, q); else hipLaunchKernelGGL((resample_mfma_kernel<false, false>), gd, bd, lds, st, q); }
   HIP_TRY(hipGetLastError());
   return MM_OK;
 }

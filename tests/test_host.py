@@ -198,15 +198,17 @@ def test_resampler_as_a_banded_gemm_on_the_host(sr_in, sr_out):
     h = h.astype(np.float32).astype(np.float64)
     tb = banded_tables(L, M, h, half)
     F, S, NB, ks = tb["F"], tb["S"], tb["NB"], tb["ksteps"]
-    assert F % 16 == 0 and F % L == 0 and S * L == F * M and NB == F // 16
+    assert F >= 16 and F % L == 0 and S * L == F * M and NB == -(-F // 16) and 16 * NB <= 1.13 * F
     assert ks % 8 == 0 and tb["atab"].shape == (NB, ks // 4, 64, 4) and tb["lo_off"].shape == (NB,) and tb["lo_off"][0] == 0
     assert tb["win"] == int(tb["lo_off"].max()) + 4 * ks
-    for b in (0, NB - 1):                       # lane l of step s holds A[b][r = l % 16][k = 4 s + l // 16]
-        for s_ in (0, ks // 2, ks - 1):
+    from modulation_mfcc_amd.audio_io import BANDED_KOFF
+    for b in (0, NB - 1):       # lane l of k-step 8 g + s holds A[b][r = l % 16][k = 32 g + KOFF[l // 16] + s]
+        for s_ in (0, 3, ks // 2 + 1, ks - 1):
             for lane in (0, 17, 35, 63):
-                assert tb["atab"][b, s_ // 4, lane, s_ % 4] == tb["A"][b, lane % 16, 4 * s_ + lane // 16]
+                k_ = 32 * (s_ // 8) + BANDED_KOFF[lane // 16] + s_ % 8
+                assert tb["atab"][b, s_ // 4, lane, s_ % 4] == tb["A"][b, lane % 16, k_]
     # every row of every block carries all of its phase's taps: row sums = the polyphase branches' DC gains
-    u = np.arange(F)
+    u = np.arange(16 * NB)
     ph = (u * M + half) % L
     want_dc = np.array([h[p_::L].sum() for p_ in ph])
     np.testing.assert_allclose(tb["A"].astype(np.float64).sum(axis=2).reshape(-1), want_dc, rtol=0, atol=1e-5)
