@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_change.hip.inc"
 #include "mm_logmel16s.hip.inc"
 #include "mm_logmel12m.hip.inc"
+#include "mm_logmel16h.hip.inc"
 #include "mm_wpf.hip.inc"
 #include "mm_hilbert.hip.inc"
 #include "mm_anyfft.hip.inc"
@@ -346,6 +347,9 @@ struct mm_plan {
   int k2_ok, wpf_r, wpf_waves, wpf_group_max;
   size_t wpf_lds_bytes;
   int num_cus;
+  float* d_h16_tab; int* d_h16_part;       // 32-frame-tile / two-workgroup experiment (mm_logmel16h.hip.inc)
+  int h16_ok, h16_n_pairs, h16_n_tab16;
+  size_t h16_lds_bytes;
   AnyPlan any;                             // any-length STFT (mm_anyfft.hip.inc): n_fft that is not a power of two in [32, 4096]
   // timing
   int timing_on;
@@ -604,6 +608,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
 
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
+  p->d_h16_tab = nullptr; p->d_h16_part = nullptr; p->h16_ok = 0;
   p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0;
   p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 0; p->s16f_red_off = 0; p->d_dctfm_a = nullptr;
   p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
@@ -750,6 +755,19 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
           hipFuncSetAttribute((const void*)logmel512w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               MM_LM_LDS_MAX) == hipSuccess)
         p->w16_ok = 1;
+      // 32-frame tiles, two 8-wave workgroups per CU (mm_logmel16h.hip.inc; opt-in variant 7): pair table from r16
+      if (31 * cfg->hop_length + 512 + 256 <= MM_H16_NR * 2048 && (cfg->hop_length % 2) == 0 && cfg->preemph == 0.0f) {
+        H16Tables ht;
+        build_h16_tables(r16, &ht);
+        p->h16_n_pairs = ht.n_pairs;
+        p->h16_n_tab16 = (int)(ht.tab.size() / 4);
+        p->h16_lds_bytes = (size_t)MM_H16_TAB_OFF + ht.tab.size() * 4;
+        if (p->h16_lds_bytes <= 80 * 1024 &&
+            upload(&p->d_h16_tab, ht.tab.data(), ht.tab.size() * 4) == MM_OK &&
+            upload(&p->d_h16_part, ht.part.data(), ht.part.size() * 4) == MM_OK &&
+            hipFuncSetAttribute((const void*)logmel512h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess)
+          p->h16_ok = 1;
+      }
       // staged-sample variant (mm_logmel16s.hip.inc): the tile's 63*hop + 512 samples must fit NR*4096 floats
       p->s16_nr = 0;
       if (p->w16_ok) {
@@ -962,6 +980,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_m12_a); (void)hipFree(p->d_m12_dct); (void)hipFree(p->d_zeros);
   (void)hipFree(p->d_dctfm_a);
   (void)hipFree(p->d_s16f_tab); (void)hipFree(p->d_s16f_dcta); (void)hipFree(p->d_s16f_part);
+  (void)hipFree(p->d_h16_tab); (void)hipFree(p->d_h16_part);
   (void)hipFree(p->any.d_tw); (void)hipFree(p->any.d_split); (void)hipFree(p->any.d_chirp); (void)hipFree(p->any.d_bhat);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
@@ -977,7 +996,7 @@ int mm_plan_config(const mm_plan* p, mm_config* out) {
 // Which fused kernel a log-mel / MFCC call runs on (mode 1; mode 0 = the power stage output).  `call`
 // = false answers for a regular call (aligned rows, n_samples >= 4).  p->variant (mm_plan_set_variant)
 // pins a variant where it applies; what a variant cannot take falls through to the next one.
-enum { MM_K_GENERIC = 0, MM_K_W8 = 1, MM_K_W16 = 2, MM_K_WPF = 3, MM_K_W16S = 4, MM_K_M12 = 5, MM_K_ANY = 6 };
+enum { MM_K_GENERIC = 0, MM_K_W8 = 1, MM_K_W16 = 2, MM_K_WPF = 3, MM_K_W16S = 4, MM_K_M12 = 5, MM_K_ANY = 6, MM_K_H16 = 7 };
 static int choose_kernel(const mm_plan* p, int mode, bool call, const float* d_audio, int64_t n_samples, int64_t stride) {
   if (p->any.ok) return MM_K_ANY;
   if (p->force_generic) return MM_K_GENERIC;
@@ -987,6 +1006,10 @@ static int choose_kernel(const mm_plan* p, int mode, bool call, const float* d_a
   // (the matrix-pipe variant is opt-in: on gfx950 v_mfma_f32_16x16x4_f32 holds the SIMD's VALU issue for its
   // whole 32 cycles -- tools/probe/mfma_f32_coexec.hip -- so the mel MFMAs do not run under the transforms
   // and the kernel measures 0.44 ms where the run-table kernel takes 0.37 ms)
+  // (the 32-frame-tile / two-workgroup experiment: opt-in, log-mel mode, plain aligned rows, length a multiple of 4)
+  if (v == MM_K_H16 && p->h16_ok && mode == 1 &&
+      (!call || (n_samples >= 4 && (n_samples % 4) == 0 && (stride % 4) == 0 && (((uintptr_t)d_audio) & 15) == 0)))
+    return MM_K_H16;
   const bool m12_ok = p->m12_ok && mode == 1 && n4 && v == MM_K_M12;
   const bool staged_ok = p->s16_nr && p->w16_ok && n4 && v != MM_K_W16 && v != MM_K_W8;
   const bool direct_ok = (!call || ((stride % 2) == 0 && (((uintptr_t)d_audio) & 7) == 0)) && n2 &&
@@ -1025,7 +1048,7 @@ int mm_plan_set_fuse_tail(mm_plan* p, int on) {
 }
 
 int mm_plan_set_variant(mm_plan* p, int variant) {
-  if (!p || variant < 0 || variant > MM_K_M12) return MM_ERR_INVALID_ARG;      // (MM_K_ANY is not a choice: such plans have one kernel)
+  if (!p || variant < 0 || variant > MM_K_H16 || variant == MM_K_ANY) return MM_ERR_INVALID_ARG;   // (MM_K_ANY is not a choice: such plans have one kernel)
   const int prev = p->variant;
   p->variant = variant;
   return prev;
@@ -1100,6 +1123,21 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
       if (mode == 0) hipLaunchKernelGGL((stft_any_kernel<0, 256>), dim3((unsigned)grid), dim3(256), lds, st, q);
       else hipLaunchKernelGGL((stft_any_kernel<1, 256>), dim3((unsigned)grid), dim3(256), lds, st, q);
     }
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
+  if (kern == MM_K_H16) {
+    Logmel512hParams q;
+    q.audio = d_audio; q.batch = batch; q.n_samples = n_samples; q.stride = stride;
+    q.n_frames = mm_num_frames(&p->cfg, n_samples);
+    q.tiles_per_clip = (q.n_frames + 31) / 32;
+    q.n_tiles = batch * q.tiles_per_clip;
+    q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
+    q.lane_tab = p->d_lane_tab; q.pair_tab = (const float4*)p->d_h16_tab; q.n_pairs = p->h16_n_pairs; q.n_tab16 = p->h16_n_tab16;
+    q.wave_part = p->d_h16_part; q.out_logmel = o.logmel; q.clip_key = o.key_max; q.key_nmin = o.key_nmin;
+    if (q.n_tiles > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+    const int64_t grid = std::min<int64_t>(q.n_tiles, 2 * (int64_t)p->num_cus);
+    hipLaunchKernelGGL(logmel512h_kernel, dim3((unsigned)grid), dim3(512), p->h16_lds_bytes, st, q);
     HIP_TRY(hipGetLastError());
     return MM_OK;
   }

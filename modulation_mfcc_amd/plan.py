@@ -126,7 +126,7 @@ def butter_sos(order: int, wn: float) -> np.ndarray:
     return out[:r]
 
 
-KERNEL_PATHS = ("generic", "radix16-w8", "radix16-w16", "radix16-wpf", "radix16-w16s", "radix16-m12", "any-length")
+KERNEL_PATHS = ("generic", "radix16-w8", "radix16-w16", "radix16-wpf", "radix16-w16s", "radix16-m12", "any-length", "radix16-h32")
 
 
 def _torch():

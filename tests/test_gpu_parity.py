@@ -49,7 +49,7 @@ class _variant:
         self.plan.set_variant(self.old)
 
 
-VARIANTS = ["m12", "w16s", "w16", "w8", "wpf", "generic"]
+VARIANTS = ["m12", "w16s", "h32", "w16", "w8", "wpf", "generic"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -275,6 +275,8 @@ def test_kernel_variants_selected(gpu):
     assert _plan({**kw, "hop_length": 256}).kernel_path == "radix16-w16"   # 63*hop + 512 samples > 64 KB of LDS
     with _variant(_plan(kw), "w16"):
         assert _plan(kw).kernel_path == "radix16-w16"
+    with _variant(_plan(kw), "h32"):
+        assert _plan(kw).kernel_path == "radix16-h32" and not _plan(kw).fused_dct
     assert _plan({**kw, "n_mels": 256}).kernel_path == "radix16-w8"      # mel table too big for w16
     assert _plan(load_golden("c4_am")[0]).kernel_path == "radix16-wpf"     # n_fft 2048: wave-per-frame kernel
     assert _plan(load_golden("odd_22k")[0]).kernel_path == "radix16-wpf"   # n_fft 1024, even hop
