@@ -1,5 +1,6 @@
 """dev helper (GPU box): randomized parity sweep, larger than the test suite's -- random configurations
-(biased towards the radix-16 kernels) x ragged clip lengths incl. multiples of 4 (staged-sample kernel),
+(biased towards the radix-16 kernels; a quarter with n_fft that is not a power of two: the any-length kernel) x ragged
+clip lengths incl. multiples of 4 (staged-sample kernel),
 GPU vs the NumPy oracle with the tests' tolerance.  usage: python tools/fuzz.py [n_configs] [seed]"""
 import sys, os, warnings
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle')
@@ -18,7 +19,7 @@ def main():
     rng = np.random.default_rng(seed)
     bad = 0; paths = {}
     for idx in range(n_cfg):
-        n_fft = int(rng.choice([256, 512, 512, 512, 512, 1024, 2048]))
+        n_fft = int(rng.choice([256, 512, 512, 512, 512, 1024, 2048, 400, 600, 1000, 1536, int(rng.integers(8, 2400))]))
         win = int(rng.integers(max(2, n_fft // 4), n_fft + 1))
         hop = int(rng.integers(1, max(2, min(win, 300))))
         if rng.random() < 0.8: hop += hop & 1
