@@ -659,9 +659,40 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       mm_plan_destroy(p);
       return rc;
     }
-    const void* kfn[4] = {(const void*)stft_any_kernel<0, 64>, (const void*)stft_any_kernel<1, 64>,
-                          (const void*)stft_any_kernel<0, 256>, (const void*)stft_any_kernel<1, 256>};
-    for (int i = 0; i < 4; ++i)
+    {
+      // LDSTAB: the constant tables packed into one array (window | tw | split | chirp | mel_w | mel_start | mel_len |
+      // mel_off), copied to LDS by every workgroup when they fit beside the frame buffers (64 KB budget with a wave per
+      // frame, so that several workgroups stay resident; the whole LDS with a workgroup per frame)
+      AnyPlan& ap = p->any;
+      std::vector<float> pack(win.begin(), win.end());
+      auto put = [&](const void* src, size_t n_floats) {
+        const int off = (int)pack.size();
+        pack.resize(pack.size() + ((n_floats + 3) & ~(size_t)3), 0.0f);
+        if (n_floats) std::memcpy(pack.data() + off, src, n_floats * 4);
+        return off;
+      };
+      ap.o_tw = put(atw.data(), atw.size());
+      ap.o_split = put(asplit.data(), asplit.size());
+      ap.o_chirp = put(achirp.data(), achirp.size());
+      ap.o_melw = put(csr.w.data(), csr.w.size());
+      ap.o_mstart = put(csr.start.data(), csr.start.size());
+      ap.o_mlen = put(csr.len.data(), csr.len.size());
+      ap.o_moff = put(csr.off.data(), csr.off.size());
+      ap.tab_floats = (int)pack.size();
+      const size_t G = 256 / ap.tpf, budget = ap.tpf == 64 ? 65536 : MM_LM_LDS_MAX;
+      // (direct lengths only: the Bluestein path's radix-2 stages are LDS-bound already -- with its twiddles in LDS too
+      // n_fft 499 took 33 ms per 1 025 024 frames instead of 14.5)
+      ap.lds_tab = ap.M == 0 && G * ap.grp_bytes + pack.size() * 4 <= budget;
+      if (ap.lds_tab && (rc = upload(&ap.d_tabpack, pack.data(), pack.size() * 4))) {
+        mm_plan_destroy(p);
+        return rc;
+      }
+    }
+    const void* kfn[8] = {(const void*)stft_any_kernel<0, 64, false>, (const void*)stft_any_kernel<1, 64, false>,
+                          (const void*)stft_any_kernel<0, 256, false>, (const void*)stft_any_kernel<1, 256, false>,
+                          (const void*)stft_any_kernel<0, 64, true>, (const void*)stft_any_kernel<1, 64, true>,
+                          (const void*)stft_any_kernel<0, 256, true>, (const void*)stft_any_kernel<1, 256, true>};
+    for (int i = 0; i < 8; ++i)
       if (hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) {
         g_hip_err = "hipFuncSetAttribute(stft_any_kernel) failed";
         mm_plan_destroy(p);
@@ -982,6 +1013,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_s16f_tab); (void)hipFree(p->d_s16f_dcta); (void)hipFree(p->d_s16f_part);
   (void)hipFree(p->d_h16_tab); (void)hipFree(p->d_h16_part);
   (void)hipFree(p->any.d_tw); (void)hipFree(p->any.d_split); (void)hipFree(p->any.d_chirp); (void)hipFree(p->any.d_bhat);
+  (void)hipFree(p->any.d_tabpack);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   delete p;
   return MM_OK;
@@ -1111,18 +1143,24 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.M = ap.M; q.log2M = ap.log2M; q.tw = ap.d_tw; q.split = ap.d_split; q.chirp = ap.d_chirp; q.bhat = ap.d_bhat;
     q.mel_start = p->d_mel_start; q.mel_len = p->d_mel_len; q.mel_off = p->d_mel_off; q.mel_w = p->d_mel_w;
     q.out_power = o.power; q.out_logmel = o.logmel; q.clip_key = o.key_max;
-    q.frames_per_group = 4; q.grp_bytes = ap.grp_bytes; q.b_off = ap.b_off; q.p_off = ap.p_off;
+    // with the tables in LDS a thread group takes 16 consecutive frames (the copy is paid once per 64 / 16 frames)
+    q.frames_per_group = ap.lds_tab ? 16 : 4; q.grp_bytes = ap.grp_bytes; q.b_off = ap.b_off; q.p_off = ap.p_off;
+    q.tabpack = ap.d_tabpack; q.tab_floats = ap.tab_floats; q.o_tw = ap.o_tw; q.o_split = ap.o_split; q.o_chirp = ap.o_chirp;
+    q.o_melw = ap.o_melw; q.o_mstart = ap.o_mstart; q.o_mlen = ap.o_mlen; q.o_moff = ap.o_moff;
     const int G = 256 / ap.tpf, fpb = G * q.frames_per_group;
     const int64_t grid = batch * ((q.n_frames + fpb - 1) / fpb);
     if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-    const size_t lds = (size_t)G * ap.grp_bytes;
-    if (ap.tpf == 64) {
-      if (mode == 0) hipLaunchKernelGGL((stft_any_kernel<0, 64>), dim3((unsigned)grid), dim3(256), lds, st, q);
-      else hipLaunchKernelGGL((stft_any_kernel<1, 64>), dim3((unsigned)grid), dim3(256), lds, st, q);
+    const size_t lds = (size_t)G * ap.grp_bytes + (ap.lds_tab ? (size_t)ap.tab_floats * 4 : 0);
+    const dim3 gd((unsigned)grid), bd(256);
+#define MM_ANY_GO(MM, TT, LL) hipLaunchKernelGGL((stft_any_kernel<MM, TT, LL>), gd, bd, lds, st, q)
+    if (ap.lds_tab) {
+      if (ap.tpf == 64) { if (mode == 0) MM_ANY_GO(0, 64, true); else MM_ANY_GO(1, 64, true); }
+      else { if (mode == 0) MM_ANY_GO(0, 256, true); else MM_ANY_GO(1, 256, true); }
     } else {
-      if (mode == 0) hipLaunchKernelGGL((stft_any_kernel<0, 256>), dim3((unsigned)grid), dim3(256), lds, st, q);
-      else hipLaunchKernelGGL((stft_any_kernel<1, 256>), dim3((unsigned)grid), dim3(256), lds, st, q);
+      if (ap.tpf == 64) { if (mode == 0) MM_ANY_GO(0, 64, false); else MM_ANY_GO(1, 64, false); }
+      else { if (mode == 0) MM_ANY_GO(0, 256, false); else MM_ANY_GO(1, 256, false); }
     }
+#undef MM_ANY_GO
     HIP_TRY(hipGetLastError());
     return MM_OK;
   }
