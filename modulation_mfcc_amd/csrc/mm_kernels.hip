@@ -1777,13 +1777,79 @@ __global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char* __
   out[(int64_t)ch * out_stride + fr] = v;
 }
 
+// 16-bit PCM, mono or stereo (what almost every WAVE file is): a thread takes 16 bytes = 8 samples with ONE load and
+// stores whole float4s per channel -- the byte-wise kernel above issues two 1-byte loads and one 4-byte store per sample
+// (0.59 ms for 256 stereo clips x 10 s x 44.1 kHz = 2.3 TB/s of bytes read + written).  Same arithmetic (q / 32768).
+extern "C++" {
+template <int CH>
+__global__ __launch_bounds__(256) void pcm_decode_s16_kernel(const uint4* __restrict__ raw, int64_t n_vec, float* __restrict__ out,
+                                                             int64_t out_stride) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += stride) {
+    const uint4 w = raw[v];
+    const unsigned u[4] = {w.x, w.y, w.z, w.w};
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = (float)(short)(u[i] & 0xFFFFu) * (1.0f / 32768.0f);
+      f[2 * i + 1] = (float)(short)(u[i] >> 16) * (1.0f / 32768.0f);
+    }
+    if (CH == 1) {
+      float4* o = reinterpret_cast<float4*>(out + 8 * v);
+      o[0] = make_float4(f[0], f[1], f[2], f[3]);
+      o[1] = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+      *reinterpret_cast<float4*>(out + 4 * v) = make_float4(f[0], f[2], f[4], f[6]);
+      *reinterpret_cast<float4*>(out + out_stride + 4 * v) = make_float4(f[1], f[3], f[5], f[7]);
+    }
+  }
+}
+// 32-bit float data, mono or stereo: 32 bytes (two 16-byte loads) per thread, 16-byte stores per channel
+template <int CH>
+__global__ __launch_bounds__(256) void pcm_decode_f32_kernel(const float4* __restrict__ raw, int64_t n_vec, float* __restrict__ out,
+                                                             int64_t out_stride) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += stride) {
+    const float4 a = raw[2 * v], b = raw[2 * v + 1];
+    if (CH == 1) {
+      float4* o = reinterpret_cast<float4*>(out + 8 * v);
+      o[0] = a; o[1] = b;
+    } else {
+      *reinterpret_cast<float4*>(out + 4 * v) = make_float4(a.x, a.z, b.x, b.z);
+      *reinterpret_cast<float4*>(out + out_stride + 4 * v) = make_float4(a.y, a.w, b.y, b.w);
+    }
+  }
+}
+}  // extern "C++"
+
 int mm_pcm_decode_f32(const void* d_raw, int32_t fmt, int32_t channels, int64_t n_frames, float* d_out, int64_t out_stride,
                       void* stream) {
   if (!d_raw || !d_out || fmt < 1 || fmt > 6 || channels < 1 || n_frames < 1 || out_stride < n_frames) return MM_ERR_INVALID_ARG;
-  const int64_t total = n_frames * channels;
-  if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(pcm_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned char*)d_raw, fmt, channels, n_frames, d_out, out_stride);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t done = 0;                                      // frames taken by the vector kernel
+  if ((fmt == 2 || fmt == 5) && (channels == 1 || channels == 2) && (((uintptr_t)d_raw | (uintptr_t)d_out) & 15) == 0 &&
+      (channels == 1 || (out_stride & 3) == 0)) {
+    const int64_t fpv = 8 / channels, n_vec = n_frames / fpv;      // a thread takes 8 samples (16 / 32 bytes)
+    if (n_vec > 0) {
+      const dim3 gd((unsigned)std::min<int64_t>((n_vec + 255) / 256, 256 * 16)), bd(256);
+      if (fmt == 2) {
+        if (channels == 1) hipLaunchKernelGGL(pcm_decode_s16_kernel<1>, gd, bd, 0, st, (const uint4*)d_raw, n_vec, d_out, out_stride);
+        else hipLaunchKernelGGL(pcm_decode_s16_kernel<2>, gd, bd, 0, st, (const uint4*)d_raw, n_vec, d_out, out_stride);
+      } else {
+        if (channels == 1) hipLaunchKernelGGL(pcm_decode_f32_kernel<1>, gd, bd, 0, st, (const float4*)d_raw, n_vec, d_out, out_stride);
+        else hipLaunchKernelGGL(pcm_decode_f32_kernel<2>, gd, bd, 0, st, (const float4*)d_raw, n_vec, d_out, out_stride);
+      }
+      done = n_vec * fpv;
+    }
+  }
+  const int64_t rest = n_frames - done;
+  if (rest > 0) {
+    const int64_t total = rest * channels;
+    if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+    const int bps = fmt == 1 ? 1 : fmt == 2 ? 2 : fmt == 3 ? 3 : fmt == 6 ? 8 : 4;
+    hipLaunchKernelGGL(pcm_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned char*)d_raw + done * channels * bps, fmt, channels, rest, d_out + done, out_stride);
+  }
   HIP_TRY(hipGetLastError());
   return MM_OK;
 }
