@@ -334,6 +334,8 @@ struct mm_plan {
   float* d_dctfm_a;                // dct_clamp_fm_mfma_kernel: A operands [kb][nk][64] (nullptr: VALU kernel)
   int dctfm_nk, dctfm_kb;
   size_t dctfm_lds;
+  float* d_dctw_a;                 // dct_clamp_fm_wave_kernel<CH>: the same, steps padded to a multiple of CH with zeros
+  int dctw_nk, dctw_ch;
   int variant;                     // mm_plan_set_variant: 0 = automatic
   int no_fuse;                     // mm_plan_set_fuse_dct(0): always run the separate clamp + DCT kernel
   int no_fuse_tail;                // mm_plan_set_fuse_tail(0): mm_mfcc_modspec_f32 always runs its separate launches
@@ -610,7 +612,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->d_h16_tab = nullptr; p->d_h16_part = nullptr; p->h16_ok = 0;
   p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0;
-  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 0; p->s16f_red_off = 0; p->d_dctfm_a = nullptr;
+  p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 0; p->s16f_red_off = 0; p->d_dctfm_a = nullptr; p->d_dctw_a = nullptr; p->dctw_nk = p->dctw_ch = 0;
   p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
   p->num_cus = 256;
   if (hipGetDevice(&p->device) != hipSuccess) {
@@ -975,6 +977,13 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
                 if (k < cfg->n_mfcc && m < cfg->n_mels) da[((size_t)kb * nk + s2) * 64 + l] = dct[(size_t)k * cfg->n_mels + m];
               }
           if (upload(&p->d_dctfm_a, da.data(), da.size() * 4) == MM_OK) { p->dctfm_nk = nk; p->dctfm_kb = kbn; p->dctfm_lds = lds; }
+          // wave-per-tile kernel: batch of 10 or 8 steps, whichever pads less
+          const int ch = ((nk + 9) / 10 * 10 <= (nk + 7) / 8 * 8) ? 10 : 8, nkp = (nk + ch - 1) / ch * ch;
+          std::vector<float> dw((size_t)kbn * nkp * 64, 0.0f);
+          for (int kb = 0; kb < kbn; ++kb)
+            std::memcpy(&dw[(size_t)kb * nkp * 64], &da[(size_t)kb * nk * 64], (size_t)nk * 64 * 4);
+          const size_t ldsw = ((size_t)kbn * nkp * 64 + 4 * 16 * (size_t)((4 * nkp) | 1)) * 4;
+          if (p->d_dctfm_a && ldsw <= 65536 && upload(&p->d_dctw_a, dw.data(), dw.size() * 4) == MM_OK) { p->dctw_nk = nkp; p->dctw_ch = ch; }
         }
       }
     }
@@ -1009,7 +1018,7 @@ int mm_plan_destroy(mm_plan* p) {
   (void)hipFree(p->d_k2_lane_tab); (void)hipFree(p->d_k2_mel_lane); (void)hipFree(p->d_window_e);
   (void)hipFree(p->d_rf2k_lane_tab);
   (void)hipFree(p->d_m12_a); (void)hipFree(p->d_m12_dct); (void)hipFree(p->d_zeros);
-  (void)hipFree(p->d_dctfm_a);
+  (void)hipFree(p->d_dctfm_a); (void)hipFree(p->d_dctw_a);
   (void)hipFree(p->d_s16f_tab); (void)hipFree(p->d_s16f_dcta); (void)hipFree(p->d_s16f_part);
   (void)hipFree(p->d_h16_tab); (void)hipFree(p->d_h16_part);
   (void)hipFree(p->any.d_tw); (void)hipFree(p->any.d_split); (void)hipFree(p->any.d_chirp); (void)hipFree(p->any.d_bhat);
@@ -1389,14 +1398,19 @@ int mm_mfcc_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_sampl
       if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
       hipLaunchKernelGGL(dct_fixup_kernel, dim3((unsigned)(batch * bpc)), dim3(256), 0, st, logmel, keys, keys + batch,
                          p->d_dct_t, d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
-    } else if (o.is_fm && p->d_dctfm_a && !p->no_fuse) {
-      // frame-major rows of the wave-per-frame kernel: clamp + DCT on the matrix pipe
-      const int64_t bpc = (T + 63) / 64;
-      if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-      const int64_t n_tiles = batch * bpc, per_cu = std::max<int64_t>(1, std::min<int64_t>(8, 163840 / (int64_t)p->dctfm_lds));
-      const int64_t grid = std::min<int64_t>(n_tiles, per_cu * p->num_cus);      // persistent: A operands loaded once
-      hipLaunchKernelGGL(dct_clamp_fm_mfma_kernel, dim3((unsigned)grid), dim3(256), p->dctfm_lds, st, logmel, keys,
-                         p->d_dctfm_a, d_mfcc, T, n_tiles, p->cfg.n_mels, p->cfg.n_mfcc, p->dctfm_nk, p->dctfm_kb, p->cfg.top_db);
+    } else if (o.is_fm && p->d_dctw_a && !p->no_fuse) {
+      // frame-major rows of the wave-per-frame kernel: clamp + DCT on the matrix pipe, a wave per 16-frame tile
+      const int64_t n_items = batch * ((T + 15) / 16);
+      const int pitch = (4 * p->dctw_nk) | 1;
+      const size_t lds = ((size_t)p->dctfm_kb * p->dctw_nk * 64 + 4 * 16 * (size_t)pitch) * 4;
+      const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, 163840 / (int64_t)lds));
+      const int64_t grid = std::min<int64_t>((n_items + 3) / 4, per_cu * p->num_cus);      // persistent: A operands loaded once
+#define MM_DCTW_GO(CC, UU, SS) hipLaunchKernelGGL((dct_clamp_fm_wave_kernel<CC, UU, SS>), dim3((unsigned)grid), dim3(256), lds, st, logmel, keys, \
+                                                  p->d_dctw_a, d_mfcc, T, n_items, p->cfg.n_mels, p->cfg.n_mfcc, p->dctw_nk, p->dctfm_kb, p->cfg.top_db)
+      if (p->dctw_ch == 10 && (p->cfg.n_mels & 3) == 0 && 16 * p->cfg.n_mels <= 5 * 256) MM_DCTW_GO(10, 5, false);   // 80 mel and below
+      else if (p->dctw_ch == 10) MM_DCTW_GO(10, 8, true);
+      else MM_DCTW_GO(8, 8, true);
+#undef MM_DCTW_GO
     } else if (o.is_fm) {
       const int64_t bpc = (T + 63) / 64;
       if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
