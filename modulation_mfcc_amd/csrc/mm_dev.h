@@ -10,6 +10,10 @@
 #define MM_STAMP_BEGIN(N)
 #define MM_STAMP_AT(i)
 #define MM_STAMP_END(N)
+#define MM_STAMP_END_BLK(N, B)
+#define MM_STAMP_FWD_DECL
+#define MM_STAMP_FWD(base)
+#define MM_STAMP_REL(i)
 #define MM_FIN_STAMP_BEGIN
 #define MM_FIN_STAMP(i)
 #endif

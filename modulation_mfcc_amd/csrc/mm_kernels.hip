@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_fft16.hip.inc"
 #include "mm_logmel16w.hip.inc"
 #include "mm_change.hip.inc"
+#include "mm_change_clip.hip.inc"
 #include "mm_logmel16s.hip.inc"
 #include "mm_logmel12m.hip.inc"
 #include "mm_logmel16h.hip.inc"
@@ -1596,6 +1597,18 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
     return MM_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   StageTimer tm(p, MM_STAGE_CHANGE, st);
+  // the clip-resident form (mm_change_clip.hip.inc): one launch, no workspace traffic
+  const ClipShape cs = clip_shape(q.n_rows, n1, n2);
+  if (!p->no_fuse_tail && f1.n_sec <= MM_CLIP_NS && f2.n_sec <= MM_CLIP_NS && cs.G >= 1 &&
+      ws_bytes >= (size_t)cs.tab_n * sizeof(double)) {
+    const int ns = std::max(f1.n_sec, f2.n_sec);
+    rc = ns <= 2 ? launch_chg_clip<2>(q, f1, f2, cs, n1, n2, q.ws1, st)
+       : ns == 3 ? launch_chg_clip<3>(q, f1, f2, cs, n1, n2, q.ws1, st)
+                 : launch_chg_clip<4>(q, f1, f2, cs, n1, n2, q.ws1, st);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
   hipLaunchKernelGGL(chg_pack_kernel, dim3((unsigned)(q.Rp / 64), (unsigned)tblocks), dim3(256), 0, st, q);
   hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p1 * q.Rp + 255) / 256)), dim3(256), 0, st,
                      q.ws1, n_frames, q.p1, q.Rp);

@@ -3,6 +3,8 @@
 Tolerance (north star / SURVEY 8(c)): MFCC within 1e-4 relative -- ``mfcc_close`` checks
 max|a-b| <= 1e-4 * max|b| per clip AND |a-b| <= 1e-4*|b| + 1e-3 elementwise.
 """
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -910,15 +912,17 @@ def test_ragged_lengths_fast_and_generic(n, gpu):
     dict(outFilter="sg", outFiltCutOff=[12], outFiltLen=15, outFiltPolyOrd=2, removeFirst=0),
     dict(outFilter="fir", outFiltCutOff=[12], outFiltLen=21),       # beyond the device stencil: host round trip
 ])
-def test_change_tail_on_device(kwargs, gpu):
+@pytest.mark.parametrize("form", ["clip", "time-major"])
+def test_change_tail_on_device(kwargs, form, gpu):
     """Row N1: mm_mfcc_change_f64 against scipy's sosfiltfilt / gradient / savgol_filter (the reference's
     tail, script/mfcc.py:392-427, both differentiators; the 'fir' / 'sg' output filters as a banded operator
-    on the device)."""
+    on the device).  Both device forms: the clip-resident launch and the time-major kernels it replaces."""
     from modulation_mfcc_amd import tail
     kw, y, exp = load_golden("refdefault_am")
     plan = _plan(kw)
     m = _dev(np.stack([exp["mfcc"], exp["mfcc"][::-1].copy() * 0.5]), gpu)      # two "clips"
-    got = tail.mfcc_change_device(plan, m, tStep=0.005, **kwargs).cpu().numpy()
+    with _change_form(plan, form):
+        got = tail.mfcc_change_device(plan, m, tStep=0.005, **kwargs).cpu().numpy()
     for i, mm in enumerate((exp["mfcc"], exp["mfcc"][::-1] * 0.5)):
         want = O.mfcc_change_tail(mm.astype(np.float32), tStep=0.005, **kwargs)
         assert got[i].shape == want.shape
@@ -927,17 +931,30 @@ def test_change_tail_on_device(kwargs, gpu):
         assert np.abs(got[i] - want).max() <= 1e-7 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("n_mfcc,B,T", [(80, 3, 400), (40, 70, 1001), (2, 5, 300)])
-def test_change_tail_many_rows_and_long_batches(n_mfcc, B, T, gpu):
-    """Row N1 beyond the reference's 13 coefficients: more rows per clip than the derivative kernel's LDS tile takes
-    (its row-walking variant), clip counts that are not a multiple of 64, the time-parallel IIR form (n >= 256) -- all
-    against scipy's sequential arithmetic."""
+@contextlib.contextmanager
+def _change_form(plan, form):
+    prev = plan.set_fuse_tail(form == "clip")
+    try:
+        yield
+    finally:
+        plan.set_fuse_tail(prev)
+
+
+@pytest.mark.parametrize("form", ["clip", "time-major"])
+@pytest.mark.parametrize("n_mfcc,B,T", [(80, 3, 400), (40, 70, 1001), (2, 5, 300), (13, 3, 3001), (13, 2, 9000),
+                                        (13, 2, 21000), (129, 2, 130), (13, 300, 100)])
+def test_change_tail_many_rows_and_long_batches(n_mfcc, B, T, form, gpu):
+    """Row N1 beyond the reference's 13 coefficients and 10 s: more rows per clip than fit LDS at once (the clip form
+    takes them in groups; the time-major derivative kernel's row-walking variant), long clips (groups of 5 rows, of one
+    row, and -- 21000 frames -- no room for a row: the time-major kernels on either setting), clip counts that are not
+    a multiple of 64, short clips (below the clip form's minimum) -- all against scipy's sequential arithmetic."""
     kw, _, _ = load_golden("c1_am")
-    plan = _plan(dict(kw, n_mels=128, n_mfcc=n_mfcc))
+    plan = _plan(dict(kw, n_mels=max(128, n_mfcc), n_mfcc=n_mfcc))
     from modulation_mfcc_amd import tail
     rng = np.random.default_rng(4)
     m = rng.standard_normal((B, n_mfcc, T)).cumsum(axis=2).astype(np.float32)
-    got = tail.mfcc_change_device(plan, _dev(m, gpu), tStep=0.01, outFiltCutOff=[12]).cpu().numpy()
+    with _change_form(plan, form):
+        got = tail.mfcc_change_device(plan, _dev(m, gpu), tStep=0.01, outFiltCutOff=[12]).cpu().numpy()
     for i in (0, B // 2, B - 1):
         want = O.mfcc_change_tail(m[i], tStep=0.01, outFiltCutOff=[12])
         assert np.abs(got[i] - want).max() <= 1e-7 * np.abs(want).max()
