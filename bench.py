@@ -254,6 +254,11 @@ def time_next_rows(torch, dev):
     ms = t(lambda: plan.mfcc_change(m, sos1, sos1))
     out["N1_change_tail_1024x13x1001"] = hbm(ms, B * K * T * 4 + B * T * 8, "MFCC rows in (f32) + change curve out (f64); the "
                                              "float64 recursion is latency-bound, DESIGN.md section 7")
+    # the recursion itself: 3 sections x (4 fma + 1 mul) = 27 flops per sample and direction, 12 rows + 1 curve per clip
+    n_ext = T + 2 * 21
+    out["N1_change_tail_1024x13x1001"]["fp64"] = flops(ms, 27.0 * 2 * (K - 1 + 1) * n_ext * B, FP64_VEC_TF, "fp64-vector",
+                                                       "sequential sosfiltfilt recursion only (what scipy executes), "
+                                                       "not the time-parallel form's extra passes")
     x = torch.randn((256, 160000), device=dev)
     ms = t(lambda: rms_batch(x, 400, 160, True))
     out["N3_rms_256x160000"] = hbm(ms, 256 * 160000 * 4 + 256 * 1001 * 4, "samples in + envelope out")

@@ -150,7 +150,8 @@ int mm_plan_set_fuse_dct(mm_plan* plan, int on);
  * n_fft 512 staged-sample kernel with its fused DCT takes the call, the trajectory length is 512 or 1024 and
  * `batch` clips spread over the compute units within 4 % (at most 32 per workgroup); 0 = the separate launches.
  * mm_plan_set_fuse_tail(plan, 0) pins the separate launches (A/B measurements, cross-checks; returns the previous
- * setting; default on). */
+ * setting; default on).  The same switch selects the device form of mm_mfcc_change_f64 (on: the clip-resident
+ * single launch; off: the time-major launches). */
 int mm_plan_fused_tail(const mm_plan* plan, int64_t batch, int64_t n_samples);
 int mm_plan_set_fuse_tail(mm_plan* plan, int on);
 /* force the generic kernels (debug / cross-check); returns previous value */
@@ -197,7 +198,16 @@ int mm_mfcc_modspec_f32(mm_plan* plan, const float* d_audio, int64_t batch, int6
  * [n_frames] f32 -> d_change [batch][n_frames] f64.  diff_method 0 = np.gradient (diffMethod='grad',
  * script/mfcc.py:405-407), 1 = savgol_filter(x, 3, 2, deriv=1, mode='interp') (any other diffMethod,
  * script/mfcc.py:409-412; needs n_frames >= 3).
- * sos1/sos2: HOST pointers to [n_sec][6] Butterworth sections (first / output filter).       */
+ * sos1/sos2: HOST pointers to [n_sec][6] Butterworth sections (first / output filter).
+ * Float64 recursion with fused multiply-adds (5 operations per section and sample); differs from scipy's
+ * evaluation order by ~1e-8 relative at most (tests: 1e-7 of the curve's maximum).
+ * Two device forms, the same arithmetic per sample (they differ by rounding, ~1e-15 relative):
+ *   - clip-resident (default whenever both filters have <= 4 sections and one MFCC row of the clip plus the curve
+ *     fit the 160 KB of LDS -- up to ~9000 frames): one launch, a workgroup per clip, the clip's rows and the curve
+ *     in LDS (rows in groups when they do not fit at once), the filters time-parallel over 64 chunks per row;
+ *     of the workspace only ~10 KB of filter tables are used (still pass mm_change_workspace_bytes());
+ *   - time-major (everything else, and after mm_plan_set_fuse_tail(plan, 0)): eight launches over a float64
+ *     workspace of [frames][rows of all clips].                                                */
 int mm_mfcc_change_f64(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_t n_frames,
                        int32_t remove_first, int32_t diff_method, const double* sos1, int32_t n_sec1,
                        const double* sos2, int32_t n_sec2, double* d_change,

@@ -241,8 +241,8 @@ class MfccPlan:
         return bool(self._lib.mm_plan_fused_tail(self._h, int(batch), int(n_samples)))
 
     def set_fuse_tail(self, on=True):
-        """on=False pins the separate launches for mfcc_modspec() (default: one launch where the plan can); returns
-        the previous setting."""
+        """on=False pins the separate launches for mfcc_modspec() (default: one launch where the plan can) and the
+        time-major kernels for mfcc_change() (default: the clip-resident single launch); returns the previous setting."""
         return bool(self._lib.mm_plan_set_fuse_tail(self._h, 1 if on else 0))
 
     def force_generic(self, on=True):
