@@ -266,6 +266,13 @@ def time_next_rows(torch, dev):
     out["N3_hilbert_256x160000"] = hbm(ms, 256 * 160000 * 8, "samples in + envelope out (the four fused FFT passes of "
                                        "the implementation move 8x that: 2.6 GB)")
     out["N3_hilbert_256x160000"]["implementation_bytes"] = 256 * 160000 * 8 * 2 * 4
+    from modulation_mfcc_amd import applyFilter
+    env = calc.hilbert_envelope_batch(x).double()
+    ms = t(lambda: applyFilter(env, 16000.0, filt="iir", cutOff=[12.0], filtLen=6))
+    out["N3_envelope_iir_filter_256x160000"] = hbm(ms, 256 * 160000 * 16, "float64 envelope in + filtered envelope out "
+                                                   "(sosfiltfilt order 6; the segmented form moves 3 x 8 B per sample and direction)")
+    out["N3_envelope_iir_filter_256x160000"]["implementation_bytes"] = 256 * 160000 * 48
+    del env
     x44 = torch.randn((256, 441000), device=dev)
     ms = t(lambda: audio_io.resample_batch(x44, 44100, 16000))
     L, M = audio_io.resample_ratio(44100, 16000)

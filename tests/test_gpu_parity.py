@@ -991,6 +991,29 @@ def test_apply_filter_on_device(filt, kw, gpu):
             applyFilter(_dev(x[:, :3 * kw["filtLen"]], gpu), sr, filt=filt, **kw)
 
 
+@pytest.mark.parametrize("order", [1, 2, 4, 6, 8, 10])
+def test_iir_filter_of_long_rows_on_device(order, gpu):
+    """applyFilter(filt='iir') on device curves of any length (the Hilbert envelope at the audio rate is 160 000 samples
+    per ten-second clip): rows cut into segments of 64 x 17 samples, a wave each -- one segment, segment boundaries
+    (n + 2 pad = 1088, 1089, 2 x 1088), more than 64 segments (several rounds of the row-level scan); Butterworth orders
+    1 - 8 on the segmented form (1 - 4 sections), order 10 on the time-major kernels; all against scipy's sequential
+    sosfiltfilt on the host."""
+    from modulation_mfcc_amd import applyFilter
+    rng = np.random.default_rng(order)
+    pad = 3 * (2 * ((order + 1) // 2) + 1 - (order % 2))
+    sr = 16000.0
+    for n in (1088 - 2 * pad, 1089 - 2 * pad, 2176 - 2 * pad, 5000, 160000):
+        rows = 3 if n > 10000 else 5
+        x = np.abs(rng.standard_normal((rows, n)).cumsum(axis=1)) + rng.standard_normal((rows, n))
+        want = np.stack([applyFilter(r, sr, filt="iir", cutOff=[12.0 if n > 10000 else 400.0], filtLen=order) for r in x])
+        got = applyFilter(_dev(x, gpu), sr, filt="iir", cutOff=[12.0 if n > 10000 else 400.0], filtLen=order)
+        assert got.is_cuda and got.shape == want.shape
+        err = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+        # a 12 Hz low-pass at 16 kHz has its poles within 5e-3 of the unit circle: scipy's own recursion carries ~1e-10
+        # of rounding there (compare orders), and so does any other evaluation order
+        assert err <= (1e-7 if n > 10000 else 1e-9), (n, err)
+
+
 @pytest.mark.parametrize("kw", [
     dict(method="gradient", difference=1), dict(method="gradient", difference=2),
     dict(method="sg", width=3, polyOrder=2, difference=1), dict(method="sg", width=7, polyOrder=3, difference=2),
