@@ -259,6 +259,11 @@ def time_next_rows(torch, dev):
     out["N1_change_tail_1024x13x1001"]["fp64"] = flops(ms, 27.0 * 2 * (K - 1 + 1) * n_ext * B, FP64_VEC_TF, "fp64-vector",
                                                        "sequential sosfiltfilt recursion only (what scipy executes), "
                                                        "not the time-parallel form's extra passes")
+    # the reference's own call shape: ONE recording (five minutes, tStep 1 ms -> 300 001 frames), the segmented-rows form
+    m1 = torch.randn((1, K, 300001), device=dev)
+    ms = t(lambda: plan.mfcc_change(m1, sos1, sos1))
+    out["N1_change_tail_one_recording_1x13x300001"] = hbm(ms, K * 300001 * 4 + 300001 * 8, "MFCC rows in (f32) + change curve out (f64)")
+    del m1
     x = torch.randn((256, 160000), device=dev)
     ms = t(lambda: rms_batch(x, 400, 160, True))
     out["N3_rms_256x160000"] = hbm(ms, 256 * 160000 * 4 + 256 * 1001 * 4, "samples in + envelope out")

@@ -201,12 +201,15 @@ int mm_mfcc_modspec_f32(mm_plan* plan, const float* d_audio, int64_t batch, int6
  * sos1/sos2: HOST pointers to [n_sec][6] Butterworth sections (first / output filter).
  * Float64 recursion with fused multiply-adds (5 operations per section and sample); differs from scipy's
  * evaluation order by ~1e-8 relative at most (tests: 1e-7 of the curve's maximum).
- * Two device forms, the same arithmetic per sample (they differ by rounding, ~1e-15 relative):
+ * Three device forms, the same arithmetic per sample (they differ by rounding, ~1e-13 relative at most):
  *   - clip-resident (default whenever both filters have <= 4 sections and one MFCC row of the clip plus the curve
  *     fit the 160 KB of LDS -- up to ~9000 frames): one launch, a workgroup per clip, the clip's rows and the curve
  *     in LDS (rows in groups when they do not fit at once), the filters time-parallel over 64 chunks per row;
  *     of the workspace only ~10 KB of filter tables are used (still pass mm_change_workspace_bytes());
- *   - time-major (everything else, and after mm_plan_set_fuse_tail(plan, 0)): eight launches over a float64
+ *   - segmented rows (fewer than 64 clips of more than 4096 frames, or rows too long for LDS -- one recording at the
+ *     reference's default 1 ms step is 10 001 frames per ten seconds): both filters through the kernels of
+ *     mm_sosfiltfilt_f64 (a wave per 1088 samples of a row), the derivative + norm between them;
+ *   - time-major (more than 4 sections, and after mm_plan_set_fuse_tail(plan, 0)): eight launches over a float64
  *     workspace of [frames][rows of all clips].                                                */
 int mm_mfcc_change_f64(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_t n_frames,
                        int32_t remove_first, int32_t diff_method, const double* sos1, int32_t n_sec1,

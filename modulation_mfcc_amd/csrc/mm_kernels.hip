@@ -1569,7 +1569,11 @@ size_t mm_change_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_fram
   // two time-major buffers [T + 2 pad][columns padded to 64]; worst-case padding 3 * (2 * MM_MAX_SEC + 1)
   const int64_t padmax = 3 * (2 * MM_MAX_SEC + 1);
   const int64_t n = n_frames + 2 * padmax;
-  return (size_t)n * (size_t)(round64(batch * p->cfg.n_mfcc) + round64(batch)) * sizeof(double);
+  const size_t tm = (size_t)n * (size_t)(round64(batch * p->cfg.n_mfcc) + round64(batch));
+  // ... or the segmented rows' buffers (mm_sos_rows.hip.inc), whichever is larger
+  const int pads = 3 * (2 * MM_CLIP_NS + 1);
+  const size_t sg = chg_seg_workspace_doubles(batch, p->cfg.n_mfcc, n_frames, pads, pads);
+  return std::max(tm, sg) * sizeof(double);
 }
 
 int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_frames,
@@ -1600,8 +1604,17 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   StageTimer tm(p, MM_STAGE_CHANGE, st);
   // the clip-resident form (mm_change_clip.hip.inc): one launch, no workspace traffic
   const ClipShape cs = clip_shape(q.n_rows, n1, n2);
-  if (!p->no_fuse_tail && f1.n_sec <= MM_CLIP_NS && f2.n_sec <= MM_CLIP_NS && cs.G >= 1 &&
-      ws_bytes >= (size_t)cs.tab_n * sizeof(double)) {
+  const bool small_sec = f1.n_sec <= MM_CLIP_NS && f2.n_sec <= MM_CLIP_NS;
+  // few long clips (one recording at a 1 ms step is 10 001 frames per ten seconds): neither a workgroup per clip nor a
+  // lane per row fills the chip -- a wave per 1088 samples of a row does (mm_sos_rows.hip.inc)
+  const bool few_long = batch < 64 && n_frames > 4096;
+  if (!p->no_fuse_tail && small_sec && (cs.G < 1 || few_long)) {
+    rc = launch_chg_segmented(q, f1, f2, q.ws1, st);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return MM_OK;
+  }
+  if (!p->no_fuse_tail && small_sec && cs.G >= 1 && ws_bytes >= (size_t)cs.tab_n * sizeof(double)) {
     const int ns = std::max(f1.n_sec, f2.n_sec);
     rc = ns <= 2 ? launch_chg_clip<2>(q, f1, f2, cs, n1, n2, q.ws1, st)
        : ns == 3 ? launch_chg_clip<3>(q, f1, f2, cs, n1, n2, q.ws1, st)
@@ -1646,9 +1659,8 @@ int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_str
   if (ws_bytes < mm_sosfiltfilt_workspace_bytes(rows, n)) return MM_ERR_WORKSPACE;
   if (f.n_sec <= MM_CLIP_NS) {     // segmented rows: a wave per 1088 samples of a row, any length
     hipStream_t st = (hipStream_t)stream;
-    rc = f.n_sec <= 2 ? launch_sos_rows<2>(f, d_x, rows, n, x_stride, d_y, (double*)d_ws, st)
-       : f.n_sec == 3 ? launch_sos_rows<3>(f, d_x, rows, n, x_stride, d_y, (double*)d_ws, st)
-                      : launch_sos_rows<4>(f, d_x, rows, n, x_stride, d_y, (double*)d_ws, st);
+    const SegSrc src = {d_x, x_stride, nullptr, 0, 0, 0};
+    rc = launch_sos_rows_any(f, src, rows, n, d_y, (double*)d_ws, st);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return MM_OK;

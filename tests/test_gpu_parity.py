@@ -942,12 +942,15 @@ def _change_form(plan, form):
 
 @pytest.mark.parametrize("form", ["clip", "time-major"])
 @pytest.mark.parametrize("n_mfcc,B,T", [(80, 3, 400), (40, 70, 1001), (2, 5, 300), (13, 3, 3001), (13, 2, 9000),
-                                        (13, 2, 21000), (129, 2, 130), (13, 300, 100)])
+                                        (13, 2, 21000), (129, 2, 130), (13, 300, 100), (13, 1, 60001), (13, 70, 9000),
+                                        (5, 3, 4097)])
 def test_change_tail_many_rows_and_long_batches(n_mfcc, B, T, form, gpu):
     """Row N1 beyond the reference's 13 coefficients and 10 s: more rows per clip than fit LDS at once (the clip form
-    takes them in groups; the time-major derivative kernel's row-walking variant), long clips (groups of 5 rows, of one
-    row, and -- 21000 frames -- no room for a row: the time-major kernels on either setting), clip counts that are not
-    a multiple of 64, short clips (below the clip form's minimum) -- all against scipy's sequential arithmetic."""
+    takes them in groups; the time-major derivative kernel's row-walking variant), long clips (13 x 3001: groups of
+    rows; 70 clips x 9000 frames: one row at a time), FEW long clips -- one recording of a minute at the reference's
+    default 1 ms step, 2 x 9000, 2 x 21000, 3 x 4097 frames: the segmented-rows form (a wave per 1088 samples) --, clip
+    counts that are not a multiple of 64, short clips -- all against scipy's sequential arithmetic, and all again on
+    the time-major kernels."""
     kw, _, _ = load_golden("c1_am")
     plan = _plan(dict(kw, n_mels=max(128, n_mfcc), n_mfcc=n_mfcc))
     from modulation_mfcc_amd import tail
