@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 120 /* 0.3.0 */
+#define MM_VERSION 121 /* 0.3.1 */
 
 typedef enum mm_status {
   MM_OK = 0,
@@ -199,15 +199,15 @@ int mm_mfcc_modspec_f32(mm_plan* plan, const float* d_audio, int64_t batch, int6
  * script/mfcc.py:405-407), 1 = savgol_filter(x, 3, 2, deriv=1, mode='interp') (any other diffMethod,
  * script/mfcc.py:409-412; needs n_frames >= 3).
  * sos1/sos2: HOST pointers to [n_sec][6] Butterworth sections (first / output filter).
- * Float64 recursion with fused multiply-adds (5 operations per section and sample); differs from scipy's
- * evaluation order by ~1e-8 relative at most (tests: 1e-7 of the curve's maximum).
+ * Float64 recursion with fused multiply-adds (5 operations per section and sample), the odd extension of the float32
+ * MFCC rows formed in float32 as scipy does on a float32 array: within ~1e-11 of scipy (tests: 1e-9 of the curve's maximum).
  * Three device forms, the same arithmetic per sample (they differ by rounding, ~1e-13 relative at most):
- *   - clip-resident (default whenever both filters have <= 4 sections and one MFCC row of the clip plus the curve
- *     fit the 160 KB of LDS -- up to ~9000 frames): one launch, a workgroup per clip, the clip's rows and the curve
+ *   - clip-resident (default for both filters <= 4 sections and clips up to ~5000 frames): one launch, a workgroup per clip, the clip's rows and the curve
  *     in LDS (rows in groups when they do not fit at once), the filters time-parallel over 64 chunks per row;
  *     of the workspace only ~10 KB of filter tables are used (still pass mm_change_workspace_bytes());
- *   - segmented rows (fewer than 64 clips of more than 4096 frames, or rows too long for LDS -- one recording at the
- *     reference's default 1 ms step is 10 001 frames per ten seconds): both filters through the kernels of
+ *   - segmented rows (clips so long that LDS holds less than a quarter of their rows at once, about 5000 frames at
+ *     12 rows -- one recording at the reference's default 1 ms step is 10 001 frames per ten seconds): both filters
+ *     through the kernels of
  *     mm_sosfiltfilt_f64 (a wave per 1088 samples of a row), the derivative + norm between them;
  *   - time-major (more than 4 sections, and after mm_plan_set_fuse_tail(plan, 0)): eight launches over a float64
  *     workspace of [frames][rows of all clips].                                                */
@@ -228,6 +228,12 @@ size_t mm_change_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_f
 int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos,
                        int32_t n_sec, double* d_y, void* d_workspace, size_t ws_bytes, void* stream);
 size_t mm_sosfiltfilt_workspace_bytes(int64_t rows, int64_t n);
+/* The same for FLOAT32 rows (librosa's RMS envelope, MFCC rows): scipy.signal.sosfiltfilt forms the odd extension
+ * `2 x[0] - x[k]` in the array's own type before its recursion upcasts, so the padded samples of a float32 curve are
+ * rounded to float32 -- this entry point does exactly that (the float64 entry point on an upcast copy differs from
+ * scipy's result on the float32 array by ~3e-9).  Same workspace. */
+int mm_sosfiltfilt_f32_f64(const float* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos,
+                           int32_t n_sec, double* d_y, void* d_workspace, size_t ws_bytes, void* stream);
 
 /* Derivative transforms of get_velocity (script/calc.py:593-650; row N2) as ONE banded linear operator
  * along time on float64 rows: interior output i = (sum_k c[k] x[i + off[k]]) / den_c; the n_edge first

@@ -104,6 +104,7 @@ PROTOTYPES = {
                                      C.c_int32, _vp, _vp, C.c_size_t, _vp]),
     "mm_sosfiltfilt_f64": (C.c_int, [_vp, _i64, _i64, _i64, _vp, C.c_int32, _vp, _vp, C.c_size_t, _vp]),
     "mm_sosfiltfilt_workspace_bytes": (C.c_size_t, [_i64, _i64]),
+    "mm_sosfiltfilt_f32_f64": (C.c_int, [_vp, _i64, _i64, _i64, _vp, C.c_int32, _vp, _vp, C.c_size_t, _vp]),
     "mm_stencil_f64": (C.c_int, [C.POINTER(mm_stencil), _vp, _i64, _i64, _i64, _vp, _vp]),
     "mm_change_workspace_bytes": (C.c_size_t, [_vp, _i64, _i64]),
     "mm_rms_num_frames": (_i64, [_i64, C.c_int32, C.c_int32, C.c_int32]),
@@ -147,7 +148,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError when the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.mm_version() < 120:
+    if lib.mm_version() < 121:
         raise ImportError("libmodmfcc.so is older than the Python binding; rebuild it")
     _lib = lib
     return lib

@@ -1605,9 +1605,14 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   // the clip-resident form (mm_change_clip.hip.inc): one launch, no workspace traffic
   const ClipShape cs = clip_shape(q.n_rows, n1, n2);
   const bool small_sec = f1.n_sec <= MM_CLIP_NS && f2.n_sec <= MM_CLIP_NS;
-  // few long clips (one recording at a 1 ms step is 10 001 frames per ten seconds): neither a workgroup per clip nor a
-  // lane per row fills the chip -- a wave per 1088 samples of a row does (mm_sos_rows.hip.inc)
-  const bool few_long = batch < 64 && n_frames > 4096;
+  // Long clips (one recording at a 1 ms step is 10 001 frames per ten seconds): the clip form holds fewer and fewer rows
+  // at once and walks its groups one after the other -- from five groups on (about 5000 frames at 12 rows) a wave per
+  // 1088 samples of a row (mm_sos_rows.hip.inc) is faster at every clip count (tools/chg_forms.py: 8001 frames 0.80 ms
+  // against 0.11 - 0.45 ms for 1 - 256 clips; 4001 frames, three groups: 0.12 against 0.11 - 0.27 ms)
+  bool few_long = cs.G >= 1 && (q.n_rows + cs.G - 1) / cs.G > 4;
+#ifdef MM_DEV
+  if (const char* e = getenv("MM_CHG_FORM")) few_long = e[0] == 's';      // side build only: A/B of the two forms (tools/chg_forms.py)
+#endif
   if (!p->no_fuse_tail && small_sec && (cs.G < 1 || few_long)) {
     rc = launch_chg_segmented(q, f1, f2, q.ws1, st);
     if (rc) return rc;
@@ -1625,7 +1630,7 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   }
   hipLaunchKernelGGL(chg_pack_kernel, dim3((unsigned)(q.Rp / 64), (unsigned)tblocks), dim3(256), 0, st, q);
   hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p1 * q.Rp + 255) / 256)), dim3(256), 0, st,
-                     q.ws1, n_frames, q.p1, q.Rp);
+                     q.ws1, n_frames, q.p1, q.Rp, 1);
   launch_sos_any(f1, q.ws1, n1, q.Rp, st);
   if (q.n_rows <= MM_CHG_MAXROWS)
     hipLaunchKernelGGL(chg_norm_kernel, dim3((unsigned)n_frames, (unsigned)(q.Bp / 64)), dim3(256), 0, st, q);
@@ -1633,7 +1638,7 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
     hipLaunchKernelGGL(chg_norm_rows_kernel, dim3((unsigned)((n_frames * q.Bp + 255) / 256)), dim3(256), 0, st, q);
   if (f2.n_sec > 0) {
     hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p2 * q.Bp + 255) / 256)), dim3(256), 0, st,
-                       q.ws2, n_frames, q.p2, q.Bp);
+                       q.ws2, n_frames, q.p2, q.Bp, 0);
     launch_sos_any(f2, q.ws2, n2, q.Bp, st);
   }
   hipLaunchKernelGGL(chg_unpack_kernel, dim3((unsigned)(q.Bp / 64), (unsigned)tblocks), dim3(256), 0, st, q);
@@ -1649,17 +1654,18 @@ size_t mm_sosfiltfilt_workspace_bytes(int64_t rows, int64_t n) {
   return std::max(tm, sg) * sizeof(double);
 }
 
-int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos, int32_t n_sec,
-                       double* d_y, void* d_ws, size_t ws_bytes, void* stream) {
-  if (!d_x || !d_y || !d_ws || rows < 1 || n < 1 || x_stride < n || n_sec < 1) return MM_ERR_INVALID_ARG;
+// d_x (float64 rows) or d_xf (float32 rows: odd extension in float32 arithmetic, see odd_ext_f32)
+static int sosfiltfilt_impl(const double* d_x, const float* d_xf, int64_t rows, int64_t n, int64_t x_stride, const double* sos,
+                            int32_t n_sec, double* d_y, void* d_ws, size_t ws_bytes, void* stream) {
+  if ((!d_x && !d_xf) || !d_y || !d_ws || rows < 1 || n < 1 || x_stride < n || n_sec < 1) return MM_ERR_INVALID_ARG;
   SosFilt f;
   int rc = make_sosfilt(sos, n_sec, &f);
   if (rc) return rc;
   if (n <= f.padlen) return MM_ERR_INVALID_ARG;      // scipy: "The length of the input vector x must be greater than padlen"
   if (ws_bytes < mm_sosfiltfilt_workspace_bytes(rows, n)) return MM_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
   if (f.n_sec <= MM_CLIP_NS) {     // segmented rows: a wave per 1088 samples of a row, any length
-    hipStream_t st = (hipStream_t)stream;
-    const SegSrc src = {d_x, x_stride, nullptr, 0, 0, 0};
+    const SegSrc src = {d_x, x_stride, d_xf, 0, 0, 0};
     rc = launch_sos_rows_any(f, src, rows, n, d_y, (double*)d_ws, st);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -1667,17 +1673,32 @@ int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_str
   }
   const int64_t Wp = round64(rows), tb = (n + 63) / 64;
   if (tb > 65535 || Wp / 64 > 0x7FFFFFFF || 2 * (int64_t)f.padlen * Wp / 256 + 1 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  hipStream_t st = (hipStream_t)stream;
   double* ws = (double*)d_ws;
-  hipLaunchKernelGGL(sos_rows_pack_kernel, dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, d_x, rows, n, x_stride,
-                     f.padlen, Wp, ws);
+  if (d_xf)
+    hipLaunchKernelGGL((sos_rows_pack_kernel<float>), dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, d_xf, rows, n,
+                       x_stride, f.padlen, Wp, ws);
+  else
+    hipLaunchKernelGGL((sos_rows_pack_kernel<double>), dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, d_x, rows, n,
+                       x_stride, f.padlen, Wp, ws);
   hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)f.padlen * Wp + 255) / 256)), dim3(256), 0, st, ws, n,
-                     f.padlen, Wp);
+                     f.padlen, Wp, d_xf ? 1 : 0);
   launch_sos_any(f, ws, n + 2 * f.padlen, Wp, st);
   hipLaunchKernelGGL(sos_rows_unpack_kernel, dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, ws, rows, n, f.padlen,
                      Wp, d_y);
   HIP_TRY(hipGetLastError());
   return MM_OK;
+}
+
+int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos, int32_t n_sec,
+                       double* d_y, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d_x) return MM_ERR_INVALID_ARG;
+  return sosfiltfilt_impl(d_x, nullptr, rows, n, x_stride, sos, n_sec, d_y, d_ws, ws_bytes, stream);
+}
+
+int mm_sosfiltfilt_f32_f64(const float* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos, int32_t n_sec,
+                           double* d_y, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d_x) return MM_ERR_INVALID_ARG;
+  return sosfiltfilt_impl(nullptr, d_x, rows, n, x_stride, sos, n_sec, d_y, d_ws, ws_bytes, stream);
 }
 
 int mm_stencil_f64(const mm_stencil* st, const double* d_x, int64_t rows, int64_t n, int64_t x_stride, double* d_y,

@@ -73,13 +73,14 @@ def _is_device_tensor(x):
 
 
 def sosfiltfilt_batch(x, sos):
-    """scipy.signal.sosfiltfilt(sos, x) along the last axis of a float64 CUDA(HIP) tensor [rows, n] (or [n])
-    on the device (mm_sosfiltfilt_f64): the recursion of applyFilter(filt='iir') for a whole batch of curves."""
+    """scipy.signal.sosfiltfilt(sos, x) along the last axis of a float64 or float32 CUDA(HIP) tensor [rows, n] (or [n])
+    on the device (mm_sosfiltfilt_f64 / _f32_f64): the recursion of applyFilter(filt='iir') for a whole batch of
+    curves; float64 result, as scipy returns for either input type."""
     import ctypes as C
     import torch
     from . import _lib
-    if not (_is_device_tensor(x) and x.dtype == torch.float64):
-        raise TypeError("x must be a float64 CUDA(HIP) tensor")
+    if not (_is_device_tensor(x) and x.dtype in (torch.float64, torch.float32)):
+        raise TypeError("x must be a float64 or float32 CUDA(HIP) tensor")
     squeeze = x.dim() == 1
     x2 = x.unsqueeze(0) if squeeze else x
     if x2.dim() != 2:
@@ -94,10 +95,13 @@ def sosfiltfilt_batch(x, sos):
     lib = _lib.load()
     out = torch.empty((rows, n), dtype=torch.float64, device=x.device)
     ws = torch.empty(int(lib.mm_sosfiltfilt_workspace_bytes(rows, n)), dtype=torch.uint8, device=x.device)
+    # float32 rows (librosa's RMS envelope ...): scipy forms their odd extension in float32 before it upcasts -- so does
+    # mm_sosfiltfilt_f32_f64; the result is float64 either way
+    fn, name = (lib.mm_sosfiltfilt_f64, "mm_sosfiltfilt_f64") if x2.dtype == torch.float64 else \
+        (lib.mm_sosfiltfilt_f32_f64, "mm_sosfiltfilt_f32_f64")
     with torch.cuda.device(x.device):
-        _lib.check(lib.mm_sosfiltfilt_f64(x2.data_ptr(), rows, n, x2.stride(0), s.ctypes.data, s.shape[0], out.data_ptr(),
-                                          ws.data_ptr(), ws.numel(),
-                                          C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "mm_sosfiltfilt_f64")
+        _lib.check(fn(x2.data_ptr(), rows, n, x2.stride(0), s.ctypes.data, s.shape[0], out.data_ptr(), ws.data_ptr(), ws.numel(),
+                      C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), name)
     return out[0] if squeeze else out
 
 
@@ -151,7 +155,9 @@ def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs)
     counts beyond the C struct (Savitzky-Golay windows over 16 samples, FIR filters over 8 taps) make the round
     trip through the host (the reference's own scipy calls)."""
     import torch
-    if x.dtype != torch.float64:
+    if filt == "iir" and x.dtype == torch.float32:
+        pass                                # float32 curves keep their type up to the kernel (odd extension in float32)
+    elif x.dtype != torch.float64:
         x = x.double()                      # scipy filters in float64 whatever the input type
     if filt == "iir":
         if coeffs is not None:

@@ -35,7 +35,7 @@ for c in range(cases):
     got = applyFilter(torch.from_numpy(x).to(dev), sr, filt="iir", cutOff=cut, filtLen=order, filtType=kind).cpu().numpy()
     err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
     worst = max(worst, err)
-    if not (err <= 1e-6):
+    if not (err <= 1e-8):
         bad += 1
         print(f"FILTER MISMATCH case {c}: order {order} {kind} cut {cut} sr {sr} rows {rows} n {n}: rel err {err:.2e}", flush=True)
 print(f"applyFilter iir: {cases} cases, {bad} mismatches, worst rel err {worst:.2e}, {time.time()-t0:.0f} s", flush=True)
@@ -66,7 +66,7 @@ for c in range(cases):
         for i in range(B):
             err = np.abs(got[i] - want[i]).max() / max(np.abs(want[i]).max(), 1e-300)
             worst2 = max(worst2, err)
-            if not (err <= 1e-6):
+            if not (err <= 1e-9):
                 bad2 += 1
                 print(f"TAIL MISMATCH case {c} form {'clip' if form else 'time-major'}: n_mfcc {n_mfcc} T {T} B {B} {kw}: {err:.2e}", flush=True)
 print(f"change tail: {cases} cases x 2 forms, {bad2} mismatches, worst rel err {worst2:.2e}, {time.time()-t0:.0f} s", flush=True)
