@@ -268,9 +268,10 @@ def time_next_rows(torch, dev):
     ms = t(lambda: rms_batch(x, 400, 160, True))
     out["N3_rms_256x160000"] = hbm(ms, 256 * 160000 * 4 + 256 * 1001 * 4, "samples in + envelope out")
     ms = t(lambda: calc.hilbert_envelope_batch(x))
-    out["N3_hilbert_256x160000"] = hbm(ms, 256 * 160000 * 8, "samples in + envelope out (the four fused FFT passes of "
-                                       "the implementation move 8x that: 2.6 GB)")
-    out["N3_hilbert_256x160000"]["implementation_bytes"] = 256 * 160000 * 8 * 2 * 4
+    out["N3_hilbert_256x160000"] = hbm(ms, 256 * 160000 * 8, "samples in + envelope out (the implementation: two clips per "
+                                       "complex transform, four fused FFT passes over 128 complex rows, the clips read "
+                                       "three times: 1.8 GB)")
+    out["N3_hilbert_256x160000"]["implementation_bytes"] = 128 * 160000 * 8 * 2 * 4 + 256 * 160000 * 4 * 3
     from modulation_mfcc_amd import applyFilter
     env = calc.hilbert_envelope_batch(x).double()
     ms = t(lambda: applyFilter(env, 16000.0, filt="iir", cutOff=[12.0], filtLen=6))

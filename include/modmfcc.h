@@ -271,10 +271,15 @@ int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t a
  * launch): mm_hilbert_fft_size() == n.  Any other length goes through Bluestein's chirp-z identity over a
  * power-of-two FFT of mm_hilbert_fft_size() = M >= 2n - 1 points.  Transforms run in the clips' own precision like
  * scipy (dtype 0: float32 / complex64, 1: float64 / complex128).
+ * Two clips share one complex transform (clip 2r in the real part, 2r + 1 in the imaginary part: the spectrum mask is
+ * linear, so the masked inverse transform returns (a - H b) + i (H a + b), and with a and b at hand both analytic
+ * signals follow); each clip is scaled by a power of two first (exact), so a quiet clip next to a loud one keeps its
+ * own relative accuracy, and a clip of zeros comes out as zeros.  A call with a single clip transforms it alone.
  * mm_hilbert_create allocates and fills the constant device tables on the current device (and synchronises);
  * mm_hilbert_envelope is asynchronous on `stream`: d_x [rows][x_stride] -> d_env [rows][env_stride], rows <=
- * 65535 per call, workspace = mm_hilbert_workspace_bytes(rows) = two [rows][fft_size] complex buffers -- size it with
- * that call, not from n (fft_size is n on the direct path, M on the Bluestein path). */
+ * 65535 per call, workspace = mm_hilbert_workspace_bytes(rows) = two [ceil(rows / 2)][fft_size] complex buffers and the
+ * clips' scale factors -- size it with that call, not from n (fft_size is n on the direct path, M on the Bluestein
+ * path). */
 typedef struct mm_hilbert mm_hilbert;
 int mm_hilbert_create(int64_t n, int32_t dtype, mm_hilbert** out);
 void mm_hilbert_destroy(mm_hilbert* h);

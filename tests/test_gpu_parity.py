@@ -1170,6 +1170,16 @@ def test_hilbert_envelope_on_device(dt, gpu):
         assert got.is_cuda and got.shape == want.shape and got.cpu().numpy().dtype == dt
         err = np.abs(got.cpu().numpy() - want).max()
         assert err <= tol * max(want.max(), 1e-30), (n, err, want.max())
+    # two clips share a complex transform (real part / imaginary part): each is scaled by a power of two first, so a
+    # quiet clip next to a loud one keeps ITS OWN relative accuracy; all-zero clips, a clip with one sample set
+    for n in (1000, 12345):
+        amp = np.array([1.0, 1e-6, 1e3, 0.0, 3e-12, 7.0, 1.0])[:, None]
+        x = (rng.standard_normal((7, n)) * amp).astype(dt)
+        x[6, :] = 0.0; x[6, n // 3] = 5.0
+        want = np.abs(scipy.signal.hilbert(x.astype(np.float64), axis=1))
+        got = calc.hilbert_envelope_batch(_dev(x, gpu)).cpu().numpy()
+        for r in range(7):
+            assert np.abs(got[r] - want[r]).max() <= tol * want[r].max() + 1e-300, (n, r, np.abs(got[r] - want[r]).max(), want[r].max())
     assert len(calc._HILBERT_PLANS) <= calc.HILBERT_MAX_PLANS          # table memory stays bounded over many lengths
     # a strided view (every other row of a bigger batch) and a single clip
     big = _dev(rng.standard_normal((6, 3001)).astype(dt), gpu)
