@@ -212,3 +212,20 @@ def test_sample_count_bound():
     src = open(os.path.join(ROOT, "modulation_mfcc_amd", "csrc", "mm_kernels.hip")).read()
     assert "#define MM_MAX_SAMPLES (((int64_t)1 << 29) - 8192)" in src
     assert "if (n_samples > MM_MAX_SAMPLES) return MM_ERR_INVALID_ARG;" in src
+
+
+def test_iir_entry_points_validate_on_the_host():
+    """mm_sosfiltfilt_f64 / _f32_f64 reject bad arguments before they touch the device; the workspace query is pure host
+    arithmetic and covers both device forms (segmented rows up to 4 sections, time-major beyond)."""
+    import numpy as np
+    lib = _lib.load()
+    sos = np.ascontiguousarray(np.array([[0.1, 0.2, 0.1, 1.0, -0.5, 0.2]]))
+    for fn in (lib.mm_sosfiltfilt_f64, lib.mm_sosfiltfilt_f32_f64):
+        assert fn(None, 4, 100, 100, sos.ctypes.data, 1, None, None, 0, None) == -1          # null pointers
+    for rows, n in ((1, 22), (256, 160000), (1024, 1001), (3, 4800000)):
+        ws = lib.mm_sosfiltfilt_workspace_bytes(rows, n)
+        n_ext = n + 2 * 27
+        seg = 8 * (1024 + 2 * rows * (-(-n_ext // 1088)) * 8 + rows * ((n_ext + 1) // 2 * 2))     # table, segment states, padded rows
+        tm = 8 * (n + 2 * 99) * (-(-rows // 64) * 64)
+        assert ws >= seg and ws >= tm and ws <= 2 * max(seg, tm)
+    assert lib.mm_sosfiltfilt_workspace_bytes(0, 100) == 0
