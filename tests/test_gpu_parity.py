@@ -1024,6 +1024,14 @@ def test_iir_filter_of_long_rows_on_device(order, gpu):
         # a 12 Hz low-pass at 16 kHz has its poles within 5e-3 of the unit circle: the states of the cascade are large
         # against its output there and the three levels of Phi products carry ~5e-10 of rounding (1e-12 otherwise)
         assert err <= (1e-8 if n > 10000 else 1e-10), (n, err)
+    # batches of 128 rows and more: a workgroup walks a row, 16 segments per round (one partial round; three rounds, the
+    # last one partial; float32 rows)
+    for rows, n, dt in ((150, 3000, np.float64), (130, 40000, np.float64), (200, 20000, np.float32)):
+        x = (np.abs(rng.standard_normal((rows, n)).cumsum(axis=1)) + rng.standard_normal((rows, n))).astype(dt)
+        got = applyFilter(_dev(x, gpu), sr, filt="iir", cutOff=[400.0], filtLen=order).cpu().numpy()
+        for r in (0, 1, rows // 2, rows - 1):
+            want = applyFilter(x[r], sr, filt="iir", cutOff=[400.0], filtLen=order)
+            assert np.abs(got[r] - want).max() <= 1e-10 * np.abs(want).max(), (rows, n, r)
 
 
 @pytest.mark.parametrize("kw", [

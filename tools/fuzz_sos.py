@@ -25,7 +25,7 @@ for c in range(cases):
     pad = 3 * (2 * nsec + 1)
     n = int(rng.choice([pad + 1, pad + 2, int(rng.integers(pad + 1, 1200)), int(rng.integers(1000, 6000)), int(rng.integers(60000, 200000))],
                        p=[0.1, 0.1, 0.4, 0.3, 0.1]))
-    rows = int(rng.integers(1, 8))
+    rows = int(rng.integers(1, 8)) if rng.random() > 0.15 or n > 20000 else int(rng.integers(128, 261))      # (>= 128 rows: a workgroup per row)
     x = rng.standard_normal((rows, n)).cumsum(axis=1) * float(rng.choice([1e-3, 1.0, 1e3])) + float(rng.normal())
     try:
         want = np.stack([applyFilter(r, sr, filt="iir", cutOff=cut, filtLen=order, filtType=kind) for r in x])
