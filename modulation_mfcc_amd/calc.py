@@ -85,9 +85,10 @@ def hilbert_envelope_batch(x):
         _HILBERT_PLANS[key] = _HilbertPlan(n, code, x.device)
     plan = _HILBERT_PLANS[key]
     lib = _lib.load()
-    per_row = int(lib.mm_hilbert_workspace_bytes(plan.h, 1))
-    chunk = max(1, min(rows, 65535, HILBERT_WS_BYTES // per_row))
-    ws = torch.empty(chunk * per_row, dtype=torch.uint8, device=x.device)
+    # two clips share one complex transform: calls of an even number of clips, sized by what a PAIR needs
+    per_pair = int(lib.mm_hilbert_workspace_bytes(plan.h, 2))
+    chunk = max(1, min(rows, 65534, 2 * (HILBERT_WS_BYTES // per_pair)))
+    ws = torch.empty(int(lib.mm_hilbert_workspace_bytes(plan.h, chunk)), dtype=torch.uint8, device=x.device)
     stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     with torch.cuda.device(x.device):
         for r0 in range(0, rows, chunk):

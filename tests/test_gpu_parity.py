@@ -1200,7 +1200,7 @@ def test_hilbert_envelope_on_device(dt, gpu):
     # more rows than one workspace-bounded call takes
     old = calc.HILBERT_WS_BYTES
     try:
-        calc.HILBERT_WS_BYTES = 3 * 2 * 8192 * (8 if dt == np.float32 else 16)      # three rows per call
+        calc.HILBERT_WS_BYTES = 3 * 2 * 8192 * (8 if dt == np.float32 else 16)      # two pairs of clips per call
         x = rng.standard_normal((8, 3000)).astype(dt)
         got = calc.hilbert_envelope_batch(_dev(x, gpu)).cpu().numpy()
     finally:
