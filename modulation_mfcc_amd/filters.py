@@ -155,7 +155,9 @@ def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs)
     counts beyond the C struct (Savitzky-Golay windows over 16 samples, FIR filters over 8 taps) make the round
     trip through the host (the reference's own scipy calls)."""
     import torch
-    if filt == "iir" and x.dtype == torch.float32:
+    was_f32 = x.dtype == torch.float32
+    x_in = x                                # (the host round trip below hands scipy the caller's own type)
+    if filt == "iir" and was_f32:
         pass                                # float32 curves keep their type up to the kernel (odd extension in float32)
     elif x.dtype != torch.float64:
         x = x.double()                      # scipy filters in float64 whatever the input type
@@ -174,7 +176,9 @@ def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs)
             raise Exception(_MSG_SG)
         from .calc import velocity_batch
         try:
-            return velocity_batch(x, 1.0, 0, "sg", filtLen, 2, polyOrd)
+            y = velocity_batch(x, 1.0, 0, "sg", filtLen, 2, polyOrd)
+            # scipy.signal.savgol_filter keeps a float32 curve float32 (it correlates in double and rounds once): so here
+            return y.float() if was_f32 else y
         except NotImplementedError:
             pass
     if filt == "fir":
@@ -189,7 +193,7 @@ def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs)
                 raise ValueError(f"The length of the input vector x must be greater than padlen, which is {3 * len(taps)}.")
             return _stencil_rows(x, st)
     if filt in ("fir", "sg"):
-        y = applyFilter(x.cpu().numpy(), sr, filt=filt, cutOff=cutOff, filtLen=filtLen,
+        y = applyFilter(x_in.cpu().numpy(), sr, filt=filt, cutOff=cutOff, filtLen=filtLen,
                         filtType=kind[:-4], polyOrd=polyOrd, coeffs=coeffs)
         return torch.from_numpy(np.ascontiguousarray(y)).to(x.device)
     raise UnboundLocalError(f"applyFilter: unknown filt {filt!r} (expected 'iir', 'fir' or 'sg')")

@@ -996,6 +996,12 @@ def test_apply_filter_on_device(filt, kw, gpu):
             got32 = applyFilter(_dev(x32, gpu), sr, filt=filt, **kw)
             assert got32.dtype == torch.float64 and want32.dtype == np.float64
             assert np.abs(got32.cpu().numpy() - want32).max() <= 1e-10 * np.abs(want32).max()
+    if filt == "sg":            # a float32 curve stays float32 (scipy correlates in double and rounds once): same values
+        x32 = x.astype(np.float32)
+        want32 = np.stack([applyFilter(r, sr, filt=filt, **kw) for r in x32])
+        got32 = applyFilter(_dev(x32, gpu), sr, filt=filt, **kw)
+        assert got32.dtype == torch.float32 and want32.dtype == np.float32
+        assert np.abs(got32.cpu().numpy() - want32).max() <= 2e-7 * np.abs(want32).max()
     one = applyFilter(_dev(x[3], gpu), sr, filt=filt, **kw).cpu().numpy()
     assert one.shape == (1001,) and np.abs(one - want[3]).max() <= 1e-10 * np.abs(want).max()
     if filt == "fir":
