@@ -189,8 +189,18 @@ def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs)
         except NotImplementedError:
             st = None
         if st is not None:
-            if x.shape[-1] <= 3 * len(taps):   # scipy.signal.filtfilt's own check and message
-                raise ValueError(f"The length of the input vector x must be greater than padlen, which is {3 * len(taps)}.")
+            pad = 3 * len(taps)
+            if x.shape[-1] <= pad:             # scipy.signal.filtfilt's own check and message
+                raise ValueError(f"The length of the input vector x must be greater than padlen, which is {pad}.")
+            if was_f32:
+                # scipy forms the odd extension of a float32 curve in float32 before lfilter upcasts (as sosfiltfilt does):
+                # extend explicitly in float32, run the operator over the extended curve (its own edge rows then only touch
+                # samples that are cropped again: pad > taps - 1), crop
+                xi = x_in if x_in.dim() == 2 else x_in.unsqueeze(0)
+                n = xi.shape[1]
+                ext = torch.cat((2 * xi[:, :1] - xi[:, 1:pad + 1].flip(1), xi, 2 * xi[:, -1:] - xi[:, n - pad - 1:n - 1].flip(1)), dim=1)
+                y = _stencil_rows(ext.double(), st)[:, pad:pad + n]
+                return y[0] if x_in.dim() == 1 else y
             return _stencil_rows(x, st)
     if filt in ("fir", "sg"):
         y = applyFilter(x_in.cpu().numpy(), sr, filt=filt, cutOff=cutOff, filtLen=filtLen,

@@ -996,6 +996,14 @@ def test_apply_filter_on_device(filt, kw, gpu):
             got32 = applyFilter(_dev(x32, gpu), sr, filt=filt, **kw)
             assert got32.dtype == torch.float64 and want32.dtype == np.float64
             assert np.abs(got32.cpu().numpy() - want32).max() <= 1e-10 * np.abs(want32).max()
+    if filt == "fir":           # a float32 curve: scipy forms filtfilt's odd extension in float32, then filters in float64
+        x32 = x.astype(np.float32)
+        want32 = np.stack([applyFilter(r, sr, filt=filt, **kw) for r in x32])
+        got32 = applyFilter(_dev(x32, gpu), sr, filt=filt, **kw)
+        assert got32.dtype == torch.float64 and want32.dtype == np.float64 and got32.shape == want32.shape
+        assert np.abs(got32.cpu().numpy() - want32).max() <= 1e-12 * np.abs(want32).max()
+        one32 = applyFilter(_dev(x32[2], gpu), sr, filt=filt, **kw).cpu().numpy()
+        assert one32.shape == (1001,) and np.abs(one32 - want32[2]).max() <= 1e-12 * np.abs(want32).max()
     if filt == "sg":            # a float32 curve stays float32 (scipy correlates in double and rounds once): same values
         x32 = x.astype(np.float32)
         want32 = np.stack([applyFilter(r, sr, filt=filt, **kw) for r in x32])
