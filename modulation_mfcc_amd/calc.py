@@ -295,10 +295,16 @@ def velocity_batch(x, sr: float, difference: int = 1, method: str = "gradient", 
                    accOrder: int = 2, polyOrder: int = 2):
     """get_velocity along the LAST axis of a float64 CUDA(HIP) tensor [rows, n] (or [n]) on the device
     (mm_stencil_f64; row N2) -- e.g. on the [B, T] output of MfccPlan.mfcc_change.  'gradient' equals
-    np.gradient(x, 1/sr) bit for bit, 'sg' / 'finDiff' agree with scipy / findiff to float64 round-off."""
+    np.gradient(x, 1/sr) bit for bit, 'sg' / 'finDiff' agree with scipy / findiff to float64 round-off.  A float32
+    tensor (an RMS envelope) comes back float32 for 'gradient' / 'sg', as numpy / scipy return it, to float32 round-off."""
     import torch
-    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64):
-        raise TypeError("x must be a float64 CUDA(HIP) tensor")
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype in (torch.float64, torch.float32)):
+        raise TypeError("x must be a float64 (or float32) CUDA(HIP) tensor")
+    if x.dtype == torch.float32:
+        # numpy / scipy keep a float32 curve float32 for 'gradient' and 'sg' (np.gradient in float32 arithmetic,
+        # savgol_filter in double, rounded once); here: float64 on the device, rounded once -- equal to float32 round-off
+        y = velocity_batch(x.double(), sr, difference, method, width, accOrder, polyOrder)
+        return y.float() if method in ("gradient", "sg") else y
     st, passes = velocity_stencil(sr, difference, method, width, accOrder, polyOrder)
     squeeze = x.dim() == 1
     x2 = x.unsqueeze(0) if squeeze else x

@@ -1080,6 +1080,12 @@ def test_velocity_on_device(kw, gpu):
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     one = get_velocity(_dev(x[0], gpu), sr, **kw).cpu().numpy()
     assert one.shape == (n,) and np.abs(one - get_velocity(x[0], sr, **kw)).max() <= 1e-12 * np.abs(want).max()
+    # a float32 curve (an RMS envelope): numpy / scipy return float32 for 'gradient' and 'sg'; so does the device path
+    x32 = x[:7].astype(np.float32)
+    want32 = np.stack([get_velocity(r, sr, **kw) for r in x32])
+    got32 = get_velocity(_dev(x32, gpu), sr, **kw)
+    assert str(got32.dtype).endswith(str(want32.dtype)), (got32.dtype, want32.dtype)
+    assert np.abs(got32.cpu().numpy().astype(np.float64) - want32).max() <= 1e-6 * np.abs(want32).max()
 
 
 def test_velocity_of_the_change_curve(gpu):
