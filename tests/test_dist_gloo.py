@@ -38,3 +38,10 @@ def test_sharded_gather_world4(n_clips):
     """Four ranks: n_clips 1 leaves three ranks EMPTY (shard_bounds(1, 4)), n_clips 5 gives shards of 2 / 1 / 1 / 1 --
     the padded equal-size slabs, the per-rank counts and the root-side concatenation with empty and uneven ranks."""
     _run_world(4, n_clips, 29620 + n_clips)
+
+
+def test_sharded_gather_world8():
+    """Eight ranks -- the shape of the driver's N = 8 launch (`torch.distributed.run --nproc-per-node 8`), on gloo: 19 clips
+    give shards of 3 / 3 / 3 / 2 / 2 / 2 / 2 / 2."""
+    assert [b - a for a, b in shard_bounds(19, 8)] == [3, 3, 3, 2, 2, 2, 2, 2]
+    _run_world(8, 19, 29650)
