@@ -165,10 +165,24 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(StftParams p) {
     const int64_t t = t0 + f;
     if (t >= p.n_frames) break;  // wave-uniform
     const int64_t base = t * p.hop - (p.n_fft >> 1);
-    for (int n = lane; n < nc; n += 64) {
-      const float x0 = load_sample(a, base + 2 * n, p.n_samples, p.preemph) * p.window[2 * n];
-      const float x1 = load_sample(a, base + 2 * n + 1, p.n_samples, p.preemph) * p.window[2 * n + 1];
-      z[__brev((unsigned)n) >> (32 - p.log2nc)] = make_float2(x0, x1);
+    // a frame inside the clip: unconditional loads, several in flight (load_sample's bounds test is a branch around
+    // every load, i.e. one round trip to memory after the other)
+    if (base >= 1 && base + p.n_fft <= p.n_samples) {
+      const float* af = a + base;
+      const float pre = p.preemph;
+#pragma unroll 4
+      for (int n = lane; n < nc; n += 64) {
+        const float xm = pre != 0.0f ? af[2 * n - 1] : 0.0f;
+        float x0 = af[2 * n], x1 = af[2 * n + 1];
+        if (pre != 0.0f) { x1 -= __fmul_rn(pre, x0); x0 -= __fmul_rn(pre, xm); }
+        z[__brev((unsigned)n) >> (32 - p.log2nc)] = make_float2(x0 * p.window[2 * n], x1 * p.window[2 * n + 1]);
+      }
+    } else {
+      for (int n = lane; n < nc; n += 64) {
+        const float x0 = load_sample(a, base + 2 * n, p.n_samples, p.preemph) * p.window[2 * n];
+        const float x1 = load_sample(a, base + 2 * n + 1, p.n_samples, p.preemph) * p.window[2 * n + 1];
+        z[__brev((unsigned)n) >> (32 - p.log2nc)] = make_float2(x0, x1);
+      }
     }
     wave_lds_sync();
     wave_cfft_lds(z, p.log2nc, p.tw, lane);
