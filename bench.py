@@ -273,11 +273,12 @@ def time_next_rows(torch, dev):
                                        "three times: 1.8 GB)")
     out["N3_hilbert_256x160000"]["implementation_bytes"] = 128 * 160000 * 8 * 2 * 4 + 256 * 160000 * 4 * 3
     from modulation_mfcc_amd import applyFilter
-    env = calc.hilbert_envelope_batch(x).double()
+    env = calc.hilbert_envelope_batch(x)                 # float32, as the reference filters it (odd extension in float32)
     ms = t(lambda: applyFilter(env, 16000.0, filt="iir", cutOff=[12.0], filtLen=6))
-    out["N3_envelope_iir_filter_256x160000"] = hbm(ms, 256 * 160000 * 16, "float64 envelope in + filtered envelope out "
-                                                   "(sosfiltfilt order 6; the segmented form moves 3 x 8 B per sample and direction)")
-    out["N3_envelope_iir_filter_256x160000"]["implementation_bytes"] = 256 * 160000 * 48
+    out["N3_envelope_iir_filter_256x160000"] = hbm(ms, 256 * 160000 * 12, "float32 envelope in + float64 filtered envelope out "
+                                                   "(sosfiltfilt order 6; a workgroup per row: one read + one write per sample "
+                                                   "and direction through a float64 workspace)")
+    out["N3_envelope_iir_filter_256x160000"]["implementation_bytes"] = 256 * 160000 * (4 + 8 + 8 + 8)
     del env
     x44 = torch.randn((256, 441000), device=dev)
     ms = t(lambda: audio_io.resample_batch(x44, 44100, 16000))
