@@ -36,19 +36,27 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 
 C16K = dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0)
 C48K = dict(sr=48000, n_fft=2048, win_length=1200, hop_length=480, n_mels=80, n_mfcc=40, fmin=100.0, fmax=10000.0)
+# the reference's OWN default call (script/main.py:732-748 -> script/mfcc.py:382-387): sr 10 kHz, tStep 5 ms -> hop 50,
+# winLen 25 ms -> win 250, n_fft 512, librosa's default 128 mel, maxFreq 10000 (above Nyquist: 26 empty filters)
+REFD = dict(sr=10000, n_fft=512, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0)
 WORKLOADS = {
     # name: (BASELINE configs index, rows per GPU, channels, seconds, cfg kwargs, with_modspec)
     "c3": (2, 1024, 1, 10.0, C16K, True),
     "c2": (1, 1024, 1, 10.0, C16K, False),
     "c4": (3, 512, 2, 10.0, C48K, False),
+    "refdefault": (None, 1024, 1, 10.0, REFD, False),
 }
+UI_CALL = dict(channelN=0, tStep=0.005, winLen=0.025, n_mfcc=13, n_fft=512, minFreq=100, maxFreq=10000, removeFirst=1,
+               filtCutoff=12, filtOrd=6, diffMethod="grad", outFilter="iir", outFiltType="low", outFiltCutOff=[12],
+               outFiltLen=6, outFiltPolyOrd=3)          # script/main.py:732-769, argument for argument
 
 
 def workload_label(name, B, T, cfg, n_mod):
     idx, _, ch, secs, _, with_mod = WORKLOADS[name]
     what = f"{B} clips" if ch == 1 else f"{B} stereo clips (both channels transformed = {B * ch} channel-rows [B, 2, n], row stride n)"
-    return (f"BASELINE configs[{idx}] per GPU: {what} x {secs:g} s x {cfg.sr:g} Hz, win {cfg.win_length} "
-            f"hop {cfg.hop_length} n_fft {cfg.n_fft}, {cfg.n_mels} mel, {cfg.n_mfcc} MFCC"
+    head = f"BASELINE configs[{idx}] per GPU" if idx is not None else "the reference's own default call (script/main.py:732-748) as a batch"
+    return (f"{head}: {what} x {secs:g} s x {cfg.sr:g} Hz, win {cfg.win_length} "
+            f"hop {cfg.hop_length} n_fft {cfg.n_fft}, {cfg.n_mels} mel (fmax {cfg.fmax:g}), {cfg.n_mfcc} MFCC"
             + (f" + modulation spectrum (rFFT {n_mod} over trajectories)" if with_mod else ""))
 
 
@@ -162,14 +170,34 @@ def _check_one(args):
     return clip, m, (O.modspec(m) if with_mod else None)
 
 
-def oracle_check_vectors(kw, n, with_mod, seeds=(90001, 90002, 90003)):
-    """Three clips of the run's signal model with their oracle MFCCs (and modulation spectra), computed in forked
-    workers BEFORE this process touches HIP -- the oracle as the checker of the timed output, never on its path.  main()
-    writes the clips into rows 0, R/2 and R-1 of the device batch and compares those output rows after the timed region."""
+def oracle_check_vectors(jobs, seeds=(90001, 90002, 90003)):
+    """jobs: {name: (cfg kwargs, n_samples, with_modspec)} -> {name: [(clip, oracle MFCC, oracle spectrum or None) x 3]}.
+    Three clips of the run's signal model per workload with their oracle answers, computed in forked workers BEFORE
+    this process touches HIP -- the oracle as the checker of the timed output, never on its path.  The bench writes the
+    clips into rows 0, R/2 and R-1 of each device batch and compares those output rows after the timed region."""
     import multiprocessing as mp
     ctx = mp.get_context("fork")
-    with ctx.Pool(len(seeds), initializer=_cpu_init) as pool:
-        return pool.map(_check_one, [(sd, n, kw, with_mod) for sd in seeds])
+    names = list(jobs)
+    args = [(sd, jobs[nm][1], jobs[nm][0], jobs[nm][2]) for nm in names for sd in seeds]
+    with ctx.Pool(min(len(args), 12), initializer=_cpu_init) as pool:
+        res = pool.map(_check_one, args, chunksize=1)
+    return {nm: res[i * len(seeds):(i + 1) * len(seeds)] for i, nm in enumerate(names)}
+
+
+def compare_rows(np, out_mfcc, out_mod, rows, vec):
+    """Oracle spot-check of the rows that carry the oracle's clips: worst |got - want| / max|want| (north-star bound 1e-4)."""
+    worst, worst_ms = 0.0, 0.0
+    for r_, (_, want, want_ms) in zip(rows, vec):
+        got = out_mfcc[r_].cpu().numpy()
+        worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+        if want_ms is not None and out_mod is not None:
+            gm = out_mod[r_].cpu().numpy()
+            worst_ms = max(worst_ms, float(np.abs(gm - want_ms).max() / np.abs(want_ms).max()))
+    has_ms = out_mod is not None and vec[0][2] is not None
+    return {"rows": list(rows), "max_rel": worst, "max_rel_modspec": (worst_ms if has_ms else None),
+            "tolerance": 1e-4, "ok": bool(worst <= 1e-4 and worst_ms <= 1e-4),
+            "against": "NumPy oracle (oracle/mfcc_oracle.py) on the same three clips, computed before HIP init; "
+                       "output rows of the last timed step"}
 
 
 EVENT_EVERY = 4      # dominant-kernel HIP events on every 4th timed step
@@ -299,6 +327,63 @@ def time_next_rows(torch, dev):
     return out
 
 
+def time_reference_call(torch, dev):
+    """get_MFCCS_change(path_to_a_44.1_kHz_wav, 10000, ...) EXACTLY as the reference's UI calls it (script/main.py:750-769,
+    UI_CALL above; the second variant is the function's own default tStep = 0.001, script/mfcc.py:296): wall ms per call
+    with everything the drop-in does inside it -- RIFF parse, file read, H2D, PCM decode, 44.1 -> 10 kHz resampling, MFCC,
+    change tail, D2H, Python -- beside the oracle's time for the same call on ONE host core (from the array already at
+    10 kHz: the oracle has no decoder / resampler, row N4), and the change curve checked against that oracle call."""
+    import tempfile
+    import wave
+    import numpy as np
+    from modulation_mfcc_amd import get_MFCCS_change
+    from modulation_mfcc_amd.audio_io import load_audio
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mfcc_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    sr_file, secs = 44100, 10.0
+    y = O.synth_clip(424242, int(sr_file * secs), sr_file, "am")
+    pcm = np.clip(np.round(y * 32767.0), -32768, 32767).astype("<i2")
+    out = {"call": "get_MFCCS_change(path, 10000, channelN=0, tStep=0.005, winLen=0.025, n_mfcc=13, n_fft=512, minFreq=100, "
+                   "maxFreq=10000, removeFirst=1, filtCutoff=12, filtOrd=6, diffMethod='grad', outFilter='iir', "
+                   "outFiltType='low', outFiltCutOff=[12], outFiltLen=6, outFiltPolyOrd=3) -- script/main.py:750-769",
+           "file": f"{secs:g} s mono 16-bit PCM WAVE at {sr_file} Hz"}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "clip.wav")
+        with wave.open(path, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr_file); w.writeframes(pcm.tobytes())
+        y10 = load_audio(path, 10000)[0].cpu().numpy()           # what the device hands to the MFCC stage
+        for tag, kw in (("ui_default_tStep_5ms", UI_CALL), ("function_default_tStep_1ms", dict(UI_CALL, tStep=0.001))):
+            for _ in range(3):
+                got, T = get_MFCCS_change(path, 10000, **kw)
+            torch.cuda.synchronize()
+            k = 20
+            t0 = time.perf_counter()
+            for _ in range(k):
+                got, T = get_MFCCS_change(path, 10000, **kw)
+            ms = (time.perf_counter() - t0) / k * 1e3
+            # the oracle on one core (BLAS pinned to one thread), same call on the resampled array
+            okw = dict(kw, outFiltCutOff=tuple(kw["outFiltCutOff"]))
+            lim = threadpool_limits(1) if threadpool_limits else None
+            O.get_MFCCS_change(y10, 10000, **okw)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                want, Tw = O.get_MFCCS_change(y10, 10000, **okw)
+            cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+            if lim is not None:
+                lim.unregister() if hasattr(lim, "unregister") else None
+            err = float(np.abs(got - want).max() / np.abs(want).max())
+            out[tag] = {"frames": int(len(T)), "wall_ms_per_call": round(ms, 3), "oracle_one_core_ms_per_call": round(cpu_ms, 2),
+                        "oracle_excludes": "WAVE decode and the 44.1 -> 10 kHz resampling (soxr in the reference; row N4)",
+                        "check": {"max_rel_change_curve": err, "T_equal": bool(np.array_equal(T, Tw)), "tolerance": 1e-4,
+                                  "ok": bool(err <= 1e-4 and np.array_equal(T, Tw)),
+                                  "against": "oracle.get_MFCCS_change on the device-resampled array (the suite's bound for the curve: 1e-4 of its maximum)"}}
+    return out
+
+
 def roofline_of(cfg, B, T, n_mod, with_mod, per_stage, fused_dct, traffic_key=None, fused_tail=False):
     spec_rows = 8 * (n_mod // 2 + 1) * cfg.n_mfcc / T if fused_tail else 0
     # SURVEY 8(d): ALGORITHMIC bytes of what the launch computes -- a kernel that goes from samples to MFCCs (the
@@ -383,9 +468,21 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not a.no_cpu:
         cpu = cpu_baseline(kw, int(secs * kw["sr"]), with_mod)      # no torch / HIP yet in this process
-    check_vec = None
+    check_vecs = {}
     if rank == 0 and not a.no_check:
-        check_vec = oracle_check_vectors(kw, int(secs * kw["sr"]), with_mod)
+        jobs = {a.workload: (kw, int(secs * kw["sr"]), with_mod)}
+        if world == 1 and not a.no_extra:
+            for nm in ("c2", "c4", "refdefault"):
+                if nm != a.workload:
+                    _, _, _, s_, k_, _ = WORKLOADS[nm]
+                    if k_ is kw and int(s_ * k_["sr"]) == int(secs * kw["sr"]):
+                        continue                              # same signal and configuration as the headline: shared
+                    jobs[nm] = (k_, int(s_ * k_["sr"]), nm == "refdefault")
+        check_vecs = oracle_check_vectors(jobs)
+        for nm in ("c2", "c4", "refdefault"):
+            if nm not in check_vecs and WORKLOADS[nm][4] is kw:
+                check_vecs[nm] = check_vecs[a.workload]
+    check_vec = check_vecs.get(a.workload)
 
     import torch
     import torch.distributed as dist
@@ -550,12 +647,18 @@ def main():
 
         # ---- the other single-GPU configurations, same process (N = 1 only) --------------------
         if world == 1:
-            for name in ("c2", "c4"):
+            import numpy as np
+            for name in ("c2", "c4", "refdefault"):
                 if name == a.workload:
                     continue
                 c2, p2, audio2, n2, T2 = make(name)
                 rows2 = audio2.reshape(-1, n2)
                 R2 = rows2.shape[0]
+                vec2 = check_vecs.get(name)
+                crow2 = sorted({0, R2 // 2, R2 - 1})
+                if vec2 is not None:
+                    for r_, (clip_, _, _) in zip(crow2, vec2):
+                        rows2[r_].copy_(torch.from_numpy(clip_))
                 out2 = torch.empty((R2, c2.n_mfcc, T2), dtype=torch.float32, device=dev)
                 p2.workspace(R2, n2)
                 k = max(5, a.steps // 2)
@@ -565,11 +668,37 @@ def main():
                 ex[name] = {"workload": workload_label(name, WORKLOADS[name][1], T2, c2, 0),
                              "metric": "MFCC frames/sec", "value": R2 * T2 * k / dt2, "unit": "frames/s",
                              "ms_per_step": 1e3 * dt2 / k, "steps": k, "kernel_path": p2.kernel_path,
+                             "fused_dct": bool(p2.fused_dct), "launches_per_step": len(ps),
+                             "ns_per_frame_mel": 1e9 * dt2 / k / (R2 * T2 * c2.n_mels),
                              "kernels_ms": {kk: round(v["avg_ms"], 4) for kk, v in ps.items()},
                              "roofline": roofline_of(c2, R2, T2, 0, False, ps, p2.fused_dct, key2)}
+                if vec2 is not None:
+                    ex[name]["check"] = compare_rows(np, out2, None, crow2, vec2)
+                if name == "refdefault":
+                    # the same batch through the headline entry point (MFCC + modulation spectrum of the trajectories)
+                    nm2 = c2.mod_fft_len(T2)
+                    mod2 = torch.empty((R2, c2.n_mfcc, nm2 // 2 + 1), dtype=torch.complex64, device=dev)
+                    dt3, st3 = time_steps(torch, p2, lambda: p2.mfcc_modspec(rows2, out=out2, out_mod=mod2), k, 2, ["logmel"])
+                    ps3 = {kk: {"avg_ms": v[0] / v[1], "launches": v[1]} for kk, v in st3.items()}
+                    ft3 = bool(p2.fused_tail(R2, n2))
+                    ex[name]["with_modspec"] = {
+                        "metric": "MFCC+mod-spectrum frames/sec", "value": R2 * T2 * k / dt3, "unit": "frames/s",
+                        "ms_per_step": 1e3 * dt3 / k, "steps": k, "n_mod": nm2, "fused_tail": ft3,
+                        "launches_per_step": 1 if ft3 else len(ps3),
+                        "kernels_ms": {kk: round(v["avg_ms"], 4) for kk, v in ps3.items()},
+                        "roofline": roofline_of(c2, R2, T2, nm2, True, ps3, p2.fused_dct,
+                                                "logmel512s_kernel<2" if ft3 else key2, fused_tail=ft3)}
+                    if vec2 is not None:
+                        ex[name]["with_modspec"]["check"] = compare_rows(np, out2, mod2, crow2, vec2)
+                    del mod2
                 del out2, audio2, rows2
                 torch.cuda.empty_cache()
-
+            if "c2" in ex and "refdefault" in ex:
+                ex["refdefault"]["vs_c2_per_frame_mel"] = ex["refdefault"]["ns_per_frame_mel"] / ex["c2"]["ns_per_frame_mel"]
+            try:
+                ex["refdefault_call"] = time_reference_call(torch, dev)
+            except Exception as e:
+                ex["refdefault_call"] = {"error": repr(e)}
 
         return ex
 
@@ -580,17 +709,7 @@ def main():
     check = None
     if check_vec is not None and rank == 0:
         import numpy as np
-        worst, worst_ms = 0.0, 0.0
-        for r_, (_, want, want_ms) in zip(check_rows, check_vec):
-            got = last["mfcc"][r_].cpu().numpy()
-            worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
-            if want_ms is not None and last["mod"] is not None:
-                gm = last["mod"][r_].cpu().numpy()
-                worst_ms = max(worst_ms, float(np.abs(gm - want_ms).max() / np.abs(want_ms).max()))
-        check = {"rows": check_rows, "max_rel": worst, "max_rel_modspec": (worst_ms if last["mod"] is not None else None),
-                 "tolerance": 1e-4, "ok": bool(worst <= 1e-4 and worst_ms <= 1e-4),
-                 "against": "NumPy oracle (oracle/mfcc_oracle.py) on the same three clips, computed before HIP init; "
-                            "output rows of the last timed step"}
+        check = compare_rows(np, last["mfcc"], last["mod"], check_rows, check_vec)
     frames_total = world * R * T * a.steps
     res = {
         "metric": "MFCC+mod-spectrum frames/sec" if with_mod else "MFCC frames/sec",
@@ -617,6 +736,7 @@ def main():
                                    "note": "'full' = the literal north-star split: every rank computes its own modulation "
                                            "spectrum and MFCC + modulation spectrum travel in the one gather"}
 
+    parity_failed, all_checks = False, {}
     if rank == 0:
         # ---- roofline of the dominant kernel, from HIP events recorded around every launch -----
         # the n_fft 512 tile kernels also apply the (unclamped) DCT: their launch stores the MFCC rows too
@@ -644,6 +764,18 @@ def main():
             res["per_rank"] = per_rank
         if check is not None:
             res["check"] = check
+        # every oracle check of this run in one verdict; a failed check makes the run FAIL (exit code 3 after the line)
+        def _checks(d, path=""):
+            if isinstance(d, dict):
+                for k_, v_ in d.items():
+                    if k_ == "check" and isinstance(v_, dict) and "ok" in v_:
+                        yield path + "check", v_["ok"]
+                    else:
+                        yield from _checks(v_, path + k_ + ".")
+        all_checks = dict(_checks(res))
+        res["parity_ok"] = bool(all(all_checks.values())) if all_checks else None
+        res["parity_checks"] = all_checks
+        parity_failed = res["parity_ok"] is False
         if cpu is not None:
             res["cpu_baseline"] = cpu
         sys.stdout.flush()
@@ -654,6 +786,10 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity_failed:
+        print("bench.py: an oracle check of the timed output FAILED: " + json.dumps({k: v for k, v in all_checks.items() if not v}),
+              file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

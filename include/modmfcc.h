@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 121 /* 0.3.1 */
+#define MM_VERSION 122 /* 0.3.2 */
 
 typedef enum mm_status {
   MM_OK = 0,
@@ -204,7 +204,7 @@ int mm_mfcc_modspec_f32(mm_plan* plan, const float* d_audio, int64_t batch, int6
  * Three device forms, the same arithmetic per sample (they differ by rounding, ~1e-13 relative at most):
  *   - clip-resident (default for both filters <= 4 sections and clips up to ~5000 frames): one launch, a workgroup per clip, the clip's rows and the curve
  *     in LDS (rows in groups when they do not fit at once), the filters time-parallel over 64 chunks per row;
- *     of the workspace only ~10 KB of filter tables are used (still pass mm_change_workspace_bytes());
+ *     of the workspace only ~10 KB of filter tables are used;
  *   - segmented rows (clips so long that LDS holds less than a quarter of their rows at once, about 5000 frames at
  *     12 rows -- one recording at the reference's default 1 ms step is 10 001 frames per ten seconds): both filters
  *     through the kernels of
@@ -215,7 +215,13 @@ int mm_mfcc_change_f64(mm_plan* plan, const float* d_mfcc, int64_t batch, int64_
                        int32_t remove_first, int32_t diff_method, const double* sos1, int32_t n_sec1,
                        const double* sos2, int32_t n_sec2, double* d_change,
                        void* d_workspace, size_t ws_bytes, void* stream);
+/* Workspace: mm_change_workspace_bytes_for() = what the form THIS call takes needs (same arguments as the call: a few KB
+ * for the clip-resident form, ~2 x rows x frames doubles for the other two); mm_change_workspace_bytes() = the upper
+ * bound over all forms and filters, for callers that size their buffer before they know the filters.  The call checks
+ * ws_bytes against the former. */
 size_t mm_change_workspace_bytes(const mm_plan* plan, int64_t batch, int64_t n_frames);
+size_t mm_change_workspace_bytes_for(const mm_plan* plan, int64_t batch, int64_t n_frames, int32_t remove_first,
+                                     const double* sos1, int32_t n_sec1, const double* sos2, int32_t n_sec2);
 
 /* Zero-phase IIR filter of float64 curves: scipy.signal.sosfiltfilt(sos, x) with its defaults (odd
  * extension by 3 * ntaps samples, sosfilt_zi initial state), i.e. the 'iir' branch of applyFilter

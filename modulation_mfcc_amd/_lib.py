@@ -107,6 +107,7 @@ PROTOTYPES = {
     "mm_sosfiltfilt_f32_f64": (C.c_int, [_vp, _i64, _i64, _i64, _vp, C.c_int32, _vp, _vp, C.c_size_t, _vp]),
     "mm_stencil_f64": (C.c_int, [C.POINTER(mm_stencil), _vp, _i64, _i64, _i64, _vp, _vp]),
     "mm_change_workspace_bytes": (C.c_size_t, [_vp, _i64, _i64]),
+    "mm_change_workspace_bytes_for": (C.c_size_t, [_vp, _i64, _i64, C.c_int32, _vp, C.c_int32, _vp, C.c_int32]),
     "mm_rms_num_frames": (_i64, [_i64, C.c_int32, C.c_int32, C.c_int32]),
     "mm_rms_f32": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "mm_hilbert_create": (C.c_int, [_i64, C.c_int32, C.POINTER(_vp)]),

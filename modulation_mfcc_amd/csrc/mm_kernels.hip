@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include <new>
 
 #include "mm_internal.h"
@@ -38,6 +39,23 @@ static thread_local std::string g_hip_err;
       return MM_ERR_HIP;                                                      \
     }                                                                         \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the device function object, i.e. it is kept PER DEVICE: the
+// entry points that have no plan to set it in (mm_mfcc_change_f64, mm_sosfiltfilt_*, mm_resample_banded_f32 take any
+// stream of any device) set it once per device, behind a flag indexed by hipGetDevice() -- atomic, so that two host
+// threads making their first calls at once are fine (both may set the attribute: idempotent).
+#define MM_MAX_DEV 64
+struct PerDeviceOnce { std::atomic<int> done[MM_MAX_DEV]; };
+template <class F>
+static int per_device_once(PerDeviceOnce& o, const char* what, F set) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { g_hip_err = "hipGetDevice failed"; return MM_ERR_HIP; }
+  const bool flagged = dev >= 0 && dev < MM_MAX_DEV;
+  if (flagged && o.done[dev].load(std::memory_order_acquire)) return MM_OK;
+  if (!set()) { g_hip_err = std::string("hipFuncSetAttribute(") + what + ") failed"; return MM_ERR_HIP; }
+  if (flagged) o.done[dev].store(1, std::memory_order_release);
+  return MM_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -1578,6 +1596,8 @@ static int change_pads(int n_sec1, const double* sos1, int n_sec2, const double*
 
 static int64_t round64(int64_t v) { return (v + 63) / 64 * 64; }
 
+// Upper bound over the three forms and every filter of up to MM_MAX_SEC sections (a caller that does not know its
+// filters yet); mm_change_workspace_bytes_for() sizes the form a given call takes.
 size_t mm_change_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_frames) {
   if (!p || batch < 1 || n_frames < 1) return 0;
   // two time-major buffers [T + 2 pad][columns padded to 64]; worst-case padding 3 * (2 * MM_MAX_SEC + 1)
@@ -1588,6 +1608,46 @@ size_t mm_change_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_fram
   const int pads = 3 * (2 * MM_CLIP_NS + 1);
   const size_t sg = chg_seg_workspace_doubles(batch, p->cfg.n_mfcc, n_frames, pads, pads);
   return std::max(tm, sg) * sizeof(double);
+}
+
+// Which of the three device forms a change-tail call takes, and the workspace (in doubles) THAT form needs -- one
+// routine for the size query and for the call, so the two cannot disagree.
+enum { MM_CHG_TIME_MAJOR = 0, MM_CHG_CLIP = 1, MM_CHG_SEGMENTED = 2 };
+struct ChgForm { int form; size_t need; ClipShape cs; };
+static ChgForm change_form(const mm_plan* p, int64_t batch, int64_t n_frames, int n_rows, const SosFilt& f1, const SosFilt& f2) {
+  ChgForm r;
+  const int64_t p1 = f1.padlen, p2 = f2.n_sec > 0 ? f2.padlen : 0;
+  const int64_t n1 = n_frames + 2 * p1, n2 = n_frames + 2 * p2;
+  r.cs = clip_shape(n_rows, n1, n2);
+  const bool small_sec = f1.n_sec <= MM_CLIP_NS && f2.n_sec <= MM_CLIP_NS;
+  // Long clips (one recording at a 1 ms step is 10 001 frames per ten seconds): the clip form holds fewer and fewer rows
+  // at once and walks its groups one after the other -- from five groups on (about 5000 frames at 12 rows) a wave per
+  // 1088 samples of a row (mm_sos_rows.hip.inc) is faster at every clip count (tools/chg_forms.py: 8001 frames 0.80 ms
+  // against 0.11 - 0.45 ms for 1 - 256 clips; 4001 frames, three groups: 0.12 against 0.11 - 0.27 ms)
+  bool few_long = r.cs.G >= 1 && (n_rows + r.cs.G - 1) / r.cs.G > 4;
+#ifdef MM_DEV
+  if (const char* e = getenv("MM_CHG_FORM")) few_long = e[0] == 's';      // side build only: A/B of the two forms (tools/chg_forms.py)
+#endif
+  if (!p->no_fuse_tail && small_sec && (r.cs.G < 1 || few_long)) {
+    r.form = MM_CHG_SEGMENTED;
+    r.need = chg_seg_workspace_doubles(batch, n_rows, n_frames, (int)p1, (int)p2);
+  } else if (!p->no_fuse_tail && small_sec && r.cs.G >= 1) {
+    r.form = MM_CHG_CLIP;
+    r.need = (size_t)r.cs.tab_n;        // filter tables only (a few KB): the clip lives in LDS
+  } else {
+    r.form = MM_CHG_TIME_MAJOR;         // two time-major buffers [T + 2 pad][columns padded to 64]
+    r.need = (size_t)n1 * (size_t)round64(batch * n_rows) + (size_t)n2 * (size_t)round64(batch);
+  }
+  return r;
+}
+
+size_t mm_change_workspace_bytes_for(const mm_plan* p, int64_t batch, int64_t n_frames, int32_t remove_first, const double* sos1,
+                                     int32_t n_sec1, const double* sos2, int32_t n_sec2) {
+  if (!p || batch < 1 || n_frames < 1 || remove_first < 0 || remove_first >= p->cfg.n_mfcc) return 0;
+  SosFilt f1, f2;
+  if (change_pads(n_sec1, sos1, n_sec2, sos2, &f1, &f2)) return 0;
+  const int n_rows = p->cfg.n_mfcc - (remove_first ? 1 : 0);
+  return std::max<size_t>(change_form(p, batch, n_frames, n_rows, f1, f2).need, 1) * sizeof(double);
 }
 
 int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_frames,
@@ -1602,13 +1662,15 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
   if (rc) return rc;
   // scipy: "The length of the input vector x must be greater than padlen"
   if (n_frames <= f1.padlen || n_frames <= f2.padlen) return MM_ERR_INVALID_ARG;
-  if (ws_bytes < mm_change_workspace_bytes(p, batch, n_frames)) return MM_ERR_WORKSPACE;
   ChangeParams q;
   q.mfcc = d_mfcc; q.n_frames = n_frames; q.batch = batch; q.n_mfcc = p->cfg.n_mfcc;
   q.first_row = remove_first ? 1 : 0; q.n_rows = q.n_mfcc - q.first_row;
   q.p1 = f1.padlen; q.p2 = f2.n_sec > 0 ? f2.padlen : 0; q.sg = diff_method;
   q.R = batch * q.n_rows; q.Rp = round64(q.R); q.Bp = round64(batch);
   const int64_t n1 = n_frames + 2 * q.p1, n2 = n_frames + 2 * q.p2;
+  // the workspace of the form that runs (mm_change_workspace_bytes_for); mm_change_workspace_bytes is the bound over all forms
+  const ChgForm cf = change_form(p, batch, n_frames, q.n_rows, f1, f2);
+  if (ws_bytes < cf.need * sizeof(double)) return MM_ERR_WORKSPACE;
   q.ws1 = (double*)d_ws; q.ws2 = q.ws1 + n1 * q.Rp; q.out = d_change;
   const int64_t tblocks = (n_frames + 63) / 64;
   if (tblocks > 65535 || 2 * (int64_t)q.p1 * q.Rp / 256 + 1 > 0x7FFFFFFF || n_frames * q.Bp / 256 + 1 > 0x7FFFFFFF ||
@@ -1616,24 +1678,14 @@ int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n
     return MM_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   StageTimer tm(p, MM_STAGE_CHANGE, st);
-  // the clip-resident form (mm_change_clip.hip.inc): one launch, no workspace traffic
-  const ClipShape cs = clip_shape(q.n_rows, n1, n2);
-  const bool small_sec = f1.n_sec <= MM_CLIP_NS && f2.n_sec <= MM_CLIP_NS;
-  // Long clips (one recording at a 1 ms step is 10 001 frames per ten seconds): the clip form holds fewer and fewer rows
-  // at once and walks its groups one after the other -- from five groups on (about 5000 frames at 12 rows) a wave per
-  // 1088 samples of a row (mm_sos_rows.hip.inc) is faster at every clip count (tools/chg_forms.py: 8001 frames 0.80 ms
-  // against 0.11 - 0.45 ms for 1 - 256 clips; 4001 frames, three groups: 0.12 against 0.11 - 0.27 ms)
-  bool few_long = cs.G >= 1 && (q.n_rows + cs.G - 1) / cs.G > 4;
-#ifdef MM_DEV
-  if (const char* e = getenv("MM_CHG_FORM")) few_long = e[0] == 's';      // side build only: A/B of the two forms (tools/chg_forms.py)
-#endif
-  if (!p->no_fuse_tail && small_sec && (cs.G < 1 || few_long)) {
+  if (cf.form == MM_CHG_SEGMENTED) {       // mm_sos_rows.hip.inc: a wave per 1088 samples of a row
     rc = launch_chg_segmented(q, f1, f2, q.ws1, st);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return MM_OK;
   }
-  if (!p->no_fuse_tail && small_sec && cs.G >= 1 && ws_bytes >= (size_t)cs.tab_n * sizeof(double)) {
+  if (cf.form == MM_CHG_CLIP) {            // mm_change_clip.hip.inc: one launch, no workspace traffic
+    const ClipShape& cs = cf.cs;
     const int ns = std::max(f1.n_sec, f2.n_sec);
     rc = ns <= 2 ? launch_chg_clip<2>(q, f1, f2, cs, n1, n2, q.ws1, st)
        : ns == 3 ? launch_chg_clip<3>(q, f1, f2, cs, n1, n2, q.ws1, st)
@@ -2033,7 +2085,8 @@ int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stri
 
 // The same conversion as a banded GEMM on the matrix pipe (mm_resample.hip.inc).  The host lays the taps out as MFMA A
 // operands (modulation_mfcc_amd/audio_io.py: banded_tables): d_atab [NB][ksteps][64] floats, d_lo_off [NB] int32;
-// F = lcm(L, 16) outputs per period, S = F M / L input samples per period, lo_min = first input sample (relative to a
+// F = c L >= 16 outputs per period (the host picks the smallest multiple of L that wastes <= 13 % of its last block of 16),
+// S = F M / L input samples per period, lo_min = first input sample (relative to a
 // period's origin, may be negative) of the first block's window, win = floats of one period's window union.
 int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_atab,
                            const int32_t* d_lo_off, int32_t F, int32_t S, int32_t NB, int32_t ksteps, int32_t lo_min,
@@ -2070,16 +2123,16 @@ int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t
   const int64_t periods = (n_out + F - 1) / F;
   q.tiles_per_row = (periods + 16 * QT - 1) / (16 * QT);
   q.n_items = rows * q.tiles_per_row;
-  static bool attr_done = false;
-  if (!attr_done) {
-    const void* kf[4] = {(const void*)resample_mfma_kernel<false, false>, (const void*)resample_mfma_kernel<false, true>,
-                         (const void*)resample_mfma_kernel<true, false>, (const void*)resample_mfma_kernel<true, true>};
-    for (int i = 0; i < 4; ++i)
-      if (hipFuncSetAttribute(kf[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) {
-        g_hip_err = "hipFuncSetAttribute(resample_mfma_kernel) failed";
-        return MM_ERR_HIP;
-      }
-    attr_done = true;
+  static PerDeviceOnce attr_once;
+  {
+    const int rc = per_device_once(attr_once, "resample_mfma_kernel", [] {
+      const void* kf[4] = {(const void*)resample_mfma_kernel<false, false>, (const void*)resample_mfma_kernel<false, true>,
+                           (const void*)resample_mfma_kernel<true, false>, (const void*)resample_mfma_kernel<true, true>};
+      for (int i = 0; i < 4; ++i)
+        if (hipFuncSetAttribute(kf[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) return false;
+      return true;
+    });
+    if (rc) return rc;
   }
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;

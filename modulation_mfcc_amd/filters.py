@@ -58,14 +58,24 @@ def _iir_sos_cached(sr, cut, filtLen, kind):
     return sos
 
 
+def _iir_design(sr, cutOff, filtLen, kind):
+    """The Butterworth design of applyFilter(filt='iir'), kept per argument set -- but ONLY for arguments the cache key
+    represents exactly: an integral order (int / np.integer, not bool) and numeric cut-offs.  Anything else (filtLen =
+    6.5, a string, ...) goes straight to the reference's own scipy.signal.butter call, so scipy's validation and message
+    apply ('Filter order must be a nonnegative integer') instead of a silently truncated order."""
+    if isinstance(filtLen, (int, np.integer)) and not isinstance(filtLen, (bool, np.bool_)):
+        try:
+            return _iir_sos_cached(float(sr), tuple(float(c) for c in cutOff), int(filtLen), kind)
+        except (TypeError, ValueError):
+            pass
+    return _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
+
+
 def iir_sos(sr, *, cutOff, filtLen=6, filtType="low"):
     """The Butterworth sections applyFilter(filt='iir') would use (same checks, same exceptions); the design is
     kept per argument set (host arithmetic, scipy.signal.butter)."""
     kind = _validate("iir", cutOff, filtType, sr)
-    try:
-        return _iir_sos_cached(float(sr), tuple(float(c) for c in cutOff), int(filtLen), kind).copy()
-    except (TypeError, ValueError):
-        return _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
+    return np.array(_iir_design(sr, cutOff, filtLen, kind))
 
 
 def _is_device_tensor(x):
@@ -166,10 +176,7 @@ def _apply_filter_device(x, sr, kind, *, filt, cutOff, filtLen, polyOrd, coeffs)
             sos = np.asarray(coeffs)
         else:                               # the design (host, ~0.15 ms) is kept per argument set: the device filter of
             _band_edges(cutOff, sr, kind)   # 1024 envelope rows takes less than designing it (count check first)
-            try:
-                sos = _iir_sos_cached(float(sr), tuple(float(c) for c in cutOff), int(filtLen), kind)
-            except (TypeError, ValueError):
-                sos = _sig.butter(filtLen, _band_edges(cutOff, sr, kind), btype=kind, output="sos")
+            sos = _iir_design(sr, cutOff, filtLen, kind)
         return sosfiltfilt_batch(x, sos)
     if filt == "sg":
         if len(cutOff) != 1:

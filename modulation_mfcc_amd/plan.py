@@ -376,7 +376,11 @@ class MfccPlan:
         if sg and T < 3:    # scipy.signal.savgol_filter's own check and message
             raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
         out = torch.empty((B, T), dtype=torch.float64, device=self.device)
-        need = int(self._lib.mm_change_workspace_bytes(self._h, B, T))
+        # sized by the form this call takes (a few KB for the clip-resident one), not by the bound over all forms
+        need = int(self._lib.mm_change_workspace_bytes_for(self._h, B, T, 1 if remove_first else 0, s1.ctypes.data, s1.shape[0],
+                                                           s2.ctypes.data, s2.shape[0] if out_filter else 0))
+        if need == 0:
+            raise ValueError("mm_change_workspace_bytes_for: invalid arguments")
         ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         _lib.check(self._lib.mm_mfcc_change_f64(self._h, mfcc.data_ptr(), B, T, 1 if remove_first else 0, sg,
                                                 s1.ctypes.data, s1.shape[0], s2.ctypes.data, s2.shape[0] if out_filter else 0,

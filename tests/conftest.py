@@ -68,3 +68,41 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but torch.cuda.is_available() is False")
     return torch.device("cuda", 0)
+
+
+# Published finite-difference coefficient tables (B. Fornberg, "Generation of finite difference formulas on arbitrarily
+# spaced grids", Math. Comp. 51 (1988), tables 1 and 3; unit spacing), keyed (derivative, accuracy): what
+# findiff.FinDiff(0, h, derivative, acc=accuracy) -- script/calc.py:636 -- applies: `central` inside, `forward` on the
+# first samples (the last ones take its mirror image, sign (-1)^derivative).  Numbers typed from the tables, NOT
+# computed by this repository: they pin calc._fd_weights / _findiff_first_axis and the device stencil.
+from fractions import Fraction as _F
+
+FORNBERG = {
+    (1, 2): dict(central=[_F(-1, 2), 0, _F(1, 2)], forward=[_F(-3, 2), 2, _F(-1, 2)]),
+    (1, 4): dict(central=[_F(1, 12), _F(-2, 3), 0, _F(2, 3), _F(-1, 12)],
+                 forward=[_F(-25, 12), 4, -3, _F(4, 3), _F(-1, 4)]),
+    (1, 6): dict(central=[_F(-1, 60), _F(3, 20), _F(-3, 4), 0, _F(3, 4), _F(-3, 20), _F(1, 60)],
+                 forward=[_F(-49, 20), 6, _F(-15, 2), _F(20, 3), _F(-15, 4), _F(6, 5), _F(-1, 6)]),
+    (2, 2): dict(central=[1, -2, 1], forward=[2, -5, 4, -1]),
+    (2, 4): dict(central=[_F(-1, 12), _F(4, 3), _F(-5, 2), _F(4, 3), _F(-1, 12)],
+                 forward=[_F(15, 4), _F(-77, 6), _F(107, 6), -13, _F(61, 12), _F(-5, 6)]),
+}
+
+
+def fornberg_apply(x, h, deriv, acc):
+    """The derivative findiff computes, from the hard-coded tables alone: central stencil inside, the forward stencil on
+    the first `half` samples, its mirror image on the last ones."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    c = np.array([float(v) for v in FORNBERG[(deriv, acc)]["central"]])
+    f = np.array([float(v) for v in FORNBERG[(deriv, acc)]["forward"]])
+    half = len(c) // 2
+    out = np.empty_like(x)
+    for i in range(n):
+        if i < half:
+            out[i] = f @ x[i:i + len(f)]
+        elif i >= n - half:
+            out[i] = ((-1) ** deriv) * (f @ x[i - len(f) + 1:i + 1][::-1])
+        else:
+            out[i] = c @ x[i - half:i + half + 1]
+    return out / h ** deriv

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/modmfcc.h but not exported"
     assert set(syms) == set(_lib.PROTOTYPES), set(syms) ^ set(_lib.PROTOTYPES)
-    assert lib.mm_version() == 121
+    assert lib.mm_version() == 122
     assert lib.mm_strerror(-2) == b"unsupported configuration"
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import mfcc_oracle as O
-from conftest import GOLDEN_NAMES, XCHECK_NAMES, load_golden, load_xcheck, mfcc_close
+from conftest import FORNBERG, GOLDEN_NAMES, XCHECK_NAMES, fornberg_apply, load_golden, load_xcheck, mfcc_close
 
 pytestmark = pytest.mark.gpu
 
@@ -759,6 +759,71 @@ def test_headline_config_through_the_headline_entry_point(gpu):
     assert torch.allclose(e_time, e_freq, rtol=1e-4)
 
 
+def test_configs4_workload_on_one_gpu(gpu):
+    """BASELINE configs[4]'s WORKLOAD -- 8192 clips x 10 s x 16 kHz, MFCC + modulation spectrum -- on one GPU (5.2 GB of
+    audio; the 8-GPU run gives each rank one eighth of exactly this batch).  (a) the whole batch through
+    mm_mfcc_modspec_f32: 32 clips per workgroup = MM_S16_CPW_MAX, the edge of clip mode, still ONE launch; finite,
+    Parseval on every trajectory, five spot clips (plain / quiet tail / impulse / first / last) against the oracle for
+    MFCC and spectrum.  (b) the same batch cut with dist.shard_bounds(8192, 8) -- the N = 8 partitioning -- each
+    1024-clip shard run separately: the concatenation is BIT-EQUAL to (a), MFCC and spectrum (what sharding must
+    guarantee: a clip's result does not depend on which rank or workgroup computed it).  (c) 8448 clips = 33 per
+    workgroup: past the clip-mode limit, the separate launches run (fused_tail says so) and the first 8192 clips still
+    equal (a) -- MFCC bit for bit, spectra to float32 round-off."""
+    import math
+    import torch
+    from modulation_mfcc_amd.dist import shard_bounds
+    kw, _, _ = load_golden("c1_am")
+    kw = dict(kw, fmax=8000.0)                            # bench.py C16K
+    plan = _plan(kw)
+    B, Bx, n, sr = 8192, 8448, 160000, 16000
+    g = torch.Generator(device=gpu).manual_seed(4000)
+    t = torch.arange(n, device=gpu, dtype=torch.float64) / sr
+    base = (0.3 * torch.sin(2 * math.pi * 220 * t) * (1 + 0.5 * torch.sin(2 * math.pi * 4 * t))).float()
+    big = torch.randn((Bx, n), generator=g, device=gpu, dtype=torch.float32)
+    big.mul_(0.05).add_(base[None, :])
+    big[5::64, n // 2:] *= 1e-6                           # quiet tails: these clips clamp (in-launch fix-up)
+    big[9::128] = 0.0
+    big[9::128, 70001] = 1.0                              # impulse in digital silence
+    audio = big[:B]
+    assert plan.kernel_path == "radix16-w16s" and plan.fused_dct
+    assert plan.fused_tail(B, n)                          # 32 clips per workgroup: the limit, still one launch
+    assert not plan.fused_tail(Bx, n)                     # 33: separate launches
+    m1, s1 = plan.mfcc_modspec(audio)
+    assert m1.shape == (B, 13, 1001) and s1.shape == (B, 13, 513)
+    assert bool(torch.isfinite(m1).all()) and bool(torch.isfinite(torch.view_as_real(s1)).all())
+    ocfg = O.OracleConfig(**kw)
+    for i in (0, 4100, 9 + 128 * 40, 5 + 64 * 100, B - 1):      # first, plain, impulse, quiet tail, last
+        want = O.mfcc(audio[i].cpu().numpy(), ocfg)
+        mfcc_close(m1[i].cpu().numpy(), want, f"configs[4] clip {i}")
+        wm = O.modspec(want)
+        assert np.abs(s1[i].cpu().numpy() - wm).max() <= 1e-4 * np.abs(wm).max(), f"modspec clip {i}"
+    e_time = (m1.double() ** 2).sum(-1)
+    w = torch.full((513,), 2.0, device=gpu, dtype=torch.float64)
+    w[0] = w[-1] = 1.0
+    e_freq = ((s1.real.double() ** 2 + s1.imag.double() ** 2) * w).sum(-1) / 1024
+    assert torch.allclose(e_time, e_freq, rtol=1e-4)
+    del e_time, e_freq
+    # (b) the N = 8 shards, one at a time
+    bounds = shard_bounds(B, 8)
+    assert [hi - lo for lo, hi in bounds] == [1024] * 8
+    for r, (lo, hi) in enumerate(bounds):
+        assert plan.fused_tail(hi - lo, n)
+        ms, ss = plan.mfcc_modspec(audio[lo:hi])
+        assert torch.equal(ms, m1[lo:hi]), f"shard {r}: MFCC differs from the whole-batch run"
+        assert torch.equal(torch.view_as_real(ss), torch.view_as_real(s1[lo:hi])), f"shard {r}: spectrum differs"
+    del ms, ss
+    # (c) one clip per workgroup more than clip mode takes
+    mx, sx = plan.mfcc_modspec(big)
+    assert torch.equal(mx[:B], m1)
+    err = (torch.view_as_real(sx[:B]) - torch.view_as_real(s1)).abs().amax(dim=(2, 3))
+    scale = torch.view_as_real(s1).abs().amax(dim=(2, 3))
+    assert bool((err <= 4e-7 * scale + 1e-30).all()), float((err / (scale + 1e-30)).max())
+    want = O.mfcc(big[Bx - 1].cpu().numpy(), ocfg)
+    mfcc_close(mx[Bx - 1].cpu().numpy(), want, "clip 8447 of the 33-per-workgroup batch")
+    wm = O.modspec(want)
+    assert np.abs(sx[Bx - 1].cpu().numpy() - wm).max() <= 1e-4 * np.abs(wm).max()
+
+
 # tools/fuzz.py, seed 7 (gpurun_out/fuzz_r02.log): the two configurations of 300 in which one clip fails the suite's
 # elementwise bound |a - b| <= 1e-4 |b| + 1e-3 on every kernel path while staying within 6e-6 of max|MFCC|.
 _FUZZ_PINS = [
@@ -1086,6 +1151,29 @@ def test_velocity_on_device(kw, gpu):
     got32 = get_velocity(_dev(x32, gpu), sr, **kw)
     assert str(got32.dtype).endswith(str(want32.dtype)), (got32.dtype, want32.dtype)
     assert np.abs(got32.cpu().numpy().astype(np.float64) - want32).max() <= 1e-6 * np.abs(want32).max()
+
+
+@pytest.mark.parametrize("deriv,acc", sorted(FORNBERG))
+def test_findiff_on_device_is_pinned_by_the_published_tables(deriv, acc, gpu):
+    """Row N2, 'finDiff' (script/calc.py:636: FinDiff(0, 1/sr, difference, acc=accOrder)): the device stencil against
+    Fornberg's published coefficient tables typed into conftest.FORNBERG and applied by hand (central inside, forward
+    / mirrored forward on the first / last samples) -- numbers this repository did not compute -- and against a
+    polynomial whose derivative is exact at every sample, ends included."""
+    from modulation_mfcc_amd import get_velocity
+    rng = np.random.default_rng(100 + 10 * deriv + acc)
+    sr = 200.0
+    nf = len(FORNBERG[(deriv, acc)]["forward"])
+    half = len(FORNBERG[(deriv, acc)]["central"]) // 2
+    for n in (nf + half, 64, 1001):
+        x = rng.standard_normal((9, n)).cumsum(axis=1)
+        want = np.stack([fornberg_apply(r, 1 / sr, deriv, acc) for r in x])
+        got = get_velocity(_dev(x, gpu), sr, difference=deriv, method="finDiff", accOrder=acc).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+    t = np.arange(80) / sr
+    poly = np.polynomial.Polynomial(rng.standard_normal(min(2 * half, nf - 1) + 1))
+    got = get_velocity(_dev(poly(t)[None, :], gpu), sr, difference=deriv, method="finDiff", accOrder=acc).cpu().numpy()[0]
+    exact = poly.deriv(deriv)(t)
+    assert np.abs(got - exact).max() <= 1e-8 * max(1.0, np.abs(exact).max())
 
 
 def test_velocity_of_the_change_curve(gpu):

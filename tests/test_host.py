@@ -5,7 +5,7 @@ import pytest
 import scipy.signal
 
 import mfcc_oracle as O
-from conftest import load_golden
+from conftest import FORNBERG, fornberg_apply, load_golden
 from modulation_mfcc_amd import applyFilter, calculate_amplitude_envelope, get_velocity
 from modulation_mfcc_amd import tail
 from modulation_mfcc_amd.filters import applyFilter as af2
@@ -291,3 +291,63 @@ def test_velocity_stencils_on_the_host(kw):
         assert np.abs(y - want).max() <= 1e-13 * np.abs(want).max()
     with pytest.raises(NotImplementedError):
         velocity_stencil(200.0, 1, "sg", 21, 2, 3)
+
+
+@pytest.mark.parametrize("deriv,acc", sorted(FORNBERG))
+def test_findiff_branch_is_pinned_by_the_published_tables(deriv, acc):
+    """get_velocity(method='finDiff') restates findiff.FinDiff(0, 1/sr, difference, acc=accOrder) (script/calc.py:636;
+    findiff is not installed).  Pin: (a) the weights calc._fd_weights solves for equal Fornberg's published tables
+    (conftest.FORNBERG, typed in as fractions); (b) the whole curve, edges included, equals the tables applied by
+    hand; (c) a polynomial of degree <= the stencil's exactness comes out with its exact derivative at EVERY sample
+    (interior and one-sided ends); (d) the banded operator handed to the device carries the same numbers."""
+    from modulation_mfcc_amd.calc import _fd_weights, velocity_stencil
+    tab = FORNBERG[(deriv, acc)]
+    half = len(tab["central"]) // 2
+    np.testing.assert_allclose(_fd_weights(np.arange(-half, half + 1), deriv), [float(v) for v in tab["central"]],
+                               rtol=0, atol=2e-13)
+    nf = len(tab["forward"])
+    np.testing.assert_allclose(_fd_weights(np.arange(0, nf), deriv), [float(v) for v in tab["forward"]], rtol=0, atol=5e-12)
+    rng = np.random.default_rng(deriv * 10 + acc)
+    sr = 200.0
+    for n in (nf + half, 40, 201):
+        x = rng.standard_normal(n).cumsum()
+        want = fornberg_apply(x, 1 / sr, deriv, acc)
+        got = get_velocity(x, sr, difference=deriv, method="finDiff", accOrder=acc)
+        assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+    # exactness: central weights differentiate degree <= 2*half exactly, the one-sided ones degree <= nf - 1
+    t = np.arange(60) / sr
+    deg = min(2 * half, nf - 1)
+    coef = rng.standard_normal(deg + 1)
+    poly = np.polynomial.Polynomial(coef)
+    got = get_velocity(poly(t), sr, difference=deriv, method="finDiff", accOrder=acc)
+    exact = poly.deriv(deriv)(t)
+    assert np.abs(got - exact).max() <= 1e-8 * max(1.0, np.abs(exact).max())
+    # the device operator: interior taps and the first / last rows are the table's numbers
+    st, passes = velocity_stencil(sr, deriv, "finDiff", accOrder=acc)
+    assert passes == 1 and st["off"] == list(range(-half, half + 1)) and st["n_edge"] == half
+    np.testing.assert_allclose(st["c"], [float(v) for v in tab["central"]], rtol=0, atol=2e-13)
+    for i in range(half):
+        row_l = np.zeros(st["edge_w"]); row_l[i:i + nf] = [float(v) for v in tab["forward"]]
+        np.testing.assert_allclose(st["el"][i], row_l, rtol=0, atol=5e-12)
+        row_r = np.zeros(st["edge_w"])
+        pos = st["edge_w"] - half + i
+        row_r[pos - nf + 1:pos + 1] = ((-1) ** deriv) * np.array([float(v) for v in tab["forward"]])[::-1]
+        np.testing.assert_allclose(st["er"][i], row_r, rtol=0, atol=5e-12)
+    assert st["den_c"] == st["den_e"] == (1 / sr) ** deriv
+
+
+def test_iir_design_cache_does_not_accept_what_scipy_rejects():
+    """the cached Butterworth design is keyed on int(filtLen); a non-integral order must reach
+    scipy.signal.butter -- the reference's own call (script/mfcc.py:98-101) -- and raise ITS error, not be truncated."""
+    from modulation_mfcc_amd import filters
+    a = filters.iir_sos(200.0, cutOff=[12], filtLen=6)
+    np.testing.assert_array_equal(a, scipy.signal.butter(6, 12 / 100.0, btype="lowpass", output="sos"))
+    np.testing.assert_array_equal(filters.iir_sos(200.0, cutOff=[12], filtLen=np.int64(6)), a)
+    for bad in (6.5, 5.999, True):
+        try:
+            want = scipy.signal.butter(bad, 12 / 100.0, btype="lowpass", output="sos")
+        except Exception as e:                 # what the reference's call raises for this order
+            with pytest.raises(type(e), match="Filter order"):
+                filters.iir_sos(200.0, cutOff=[12], filtLen=bad)
+        else:                                  # scipy accepts it (True == order 1): the same sections, uncached
+            np.testing.assert_array_equal(filters.iir_sos(200.0, cutOff=[12], filtLen=bad), want)

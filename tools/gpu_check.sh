@@ -23,8 +23,17 @@ for f in ("$out/${tag}_bench.json", "$out/${tag}_dist.json"):
     try:
         r = json.load(open(f))
         print(f.split("/")[-1], "value %.4g" % r["value"], "ms/step %.4f" % r["ms_per_step"], "frac", r.get("roofline", {}).get("frac"),
-              "check", r.get("check"), "per_rank", r.get("per_rank"))
+              "parity_ok", r.get("parity_ok"), r.get("parity_checks"), "per_rank", r.get("per_rank"))
+        for k in ("c2", "c4", "refdefault"):
+            if k in r:
+                print("  ", k, "ms/step %.4f" % r[k]["ms_per_step"], r[k].get("kernels_ms"), "frac", (r[k].get("roofline") or {}).get("frac"),
+                      "ns/frame.mel %.4g" % r[k].get("ns_per_frame_mel", float("nan")), r[k].get("with_modspec", {}).get("ms_per_step"))
+        if "refdefault_call" in r:
+            print("  ", json.dumps(r["refdefault_call"])[:1500])
+        if r.get("parity_ok") is False:
+            raise SystemExit("parity check failed: %r" % r.get("parity_checks"))
     except Exception as e:
         print(f, "unreadable:", e)
 PY
-exit $(( rc | rb | rd ))
+rp=$?
+exit $(( rc | rb | rd | rp ))
