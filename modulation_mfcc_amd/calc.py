@@ -285,8 +285,9 @@ def apply_stencil(x2, st, passes: int = 1):
         src = x2
         for _ in range(passes):
             out = torch.empty((rows, n), dtype=torch.float64, device=x2.device)
-            _lib.check(lib.mm_stencil_f64(C.byref(cs), src.data_ptr(), rows, n, src.stride(0), out.data_ptr(), stream),
-                       "mm_stencil_f64")
+            # (a single row's stride is arbitrary -- numpy's x[None, :] gives 0 -- and never used: pass n)
+            _lib.check(lib.mm_stencil_f64(C.byref(cs), src.data_ptr(), rows, n, src.stride(0) if rows > 1 else n,
+                                          out.data_ptr(), stream), "mm_stencil_f64")
             src = out
     return src
 

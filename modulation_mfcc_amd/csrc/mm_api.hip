@@ -4,7 +4,7 @@
 //   A1 centre-pad + frame + periodic Hann   A2 rFFT   A3 |.|^2   A4 Slaney mel   A5 dB + per-clip
 //   80 dB clamp   A6 DCT-II ortho           A8 rFFT over coefficient trajectories (build-defined)
 //
-// Kernels in this file (generic path: any power-of-two n_fft in [32, 4096], any hop):
+// Kernels in this file (mm_api.hip: plan, dispatch, the C ABI of the hot path) (generic path: any power-of-two n_fft in [32, 4096], any hop):
 //   stft_generic_kernel<MODE>  one wave per frame; half-length complex FFT (radix-2 DIT) in LDS,
 //                              real-FFT split, |.|^2, then either the power row (MODE 0) or the
 //                              CSR mel filterbank + 10*log10 + per-clip max (MODE 1)
@@ -12,130 +12,10 @@
 //   rfft_generic_kernel        stage-isolated batched rFFT of zero-padded rows (also the
 //                              trajectory rFFT of the modulation spectrum)
 // The register radix-16 kernels for n_fft 512/1024/2048 live in mm_fft16.hip.inc.
-#include <hip/hip_runtime.h>
+#include "mm_common.h"
+#include "mm_plan.h"
 
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-#include <algorithm>
-#include <atomic>
-#include <new>
-
-#include "mm_internal.h"
-#include "mm_dev.h"
-
-#define MM_TW_N 8192  // master twiddle table: exp(-2 pi i k / 8192), k < 8192 (full circle)
-
-static thread_local std::string g_hip_err;
-
-#define HIP_TRY(expr)                                                         \
-  do {                                                                        \
-    hipError_t e_ = (expr);                                                   \
-    if (e_ != hipSuccess) {                                                   \
-      g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);          \
-      return MM_ERR_HIP;                                                      \
-    }                                                                         \
-  } while (0)
-
-// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the device function object, i.e. it is kept PER DEVICE: the
-// entry points that have no plan to set it in (mm_mfcc_change_f64, mm_sosfiltfilt_*, mm_resample_banded_f32 take any
-// stream of any device) set it once per device, behind a flag indexed by hipGetDevice() -- atomic, so that two host
-// threads making their first calls at once are fine (both may set the attribute: idempotent).
-#define MM_MAX_DEV 64
-struct PerDeviceOnce { std::atomic<int> done[MM_MAX_DEV]; };
-template <class F>
-static int per_device_once(PerDeviceOnce& o, const char* what, F set) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { g_hip_err = "hipGetDevice failed"; return MM_ERR_HIP; }
-  const bool flagged = dev >= 0 && dev < MM_MAX_DEV;
-  if (flagged && o.done[dev].load(std::memory_order_acquire)) return MM_OK;
-  if (!set()) { g_hip_err = std::string("hipFuncSetAttribute(") + what + ") failed"; return MM_ERR_HIP; }
-  if (flagged) o.done[dev].store(1, std::memory_order_release);
-  return MM_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_sync() {
-  // LDS operations of ONE wave execute in order; this only stops the compiler from moving
-  // accesses across the point where lanes exchange data through the wave-private buffer.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every
-// global load / store / atomic in flight: in the persistent fused kernels that exposes a full
-// memory round trip per tile (the next tile's prefetch before phase B, the log-mel stores after it).
-__device__ __forceinline__ void wg_barrier_lds() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-// order-preserving float -> int key for atomicMax
-__device__ __forceinline__ int float_key(float f) {
-  int i = __float_as_int(f);
-  return i >= 0 ? i : i ^ 0x7FFFFFFF;
-}
-__device__ __forceinline__ float key_float(int k) {
-  return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF);
-}
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-typedef float mm_f32x4 __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f32_16x16x4_f32
-
-// In-place radix-2 DIT over a wave-private LDS buffer; input already bit-reversed.
-__device__ __forceinline__ void wave_cfft_lds(float2* z, int log2nc, const float2* __restrict__ tw,
-                                              int lane) {
-  const int nc = 1 << log2nc;
-  for (int s = 1; s <= log2nc; ++s) {
-    const int half = 1 << (s - 1);
-    const int tw_stride = MM_TW_N >> s;
-    for (int j = lane; j < (nc >> 1); j += 64) {
-      const int pos = j & (half - 1);
-      const int i0 = ((j >> (s - 1)) << s) + pos;
-      const int i1 = i0 + half;
-      const float2 w = tw[pos * tw_stride];
-      const float2 a = z[i0];
-      const float2 t = cmul(w, z[i1]);
-      z[i0] = make_float2(a.x + t.x, a.y + t.y);
-      z[i1] = make_float2(a.x - t.x, a.y - t.y);
-    }
-    wave_lds_sync();
-  }
-}
-
-// Split the half-length complex FFT Z (nc points, in LDS) of a packed real row into the real
-// FFT bins k and nc-k.  Returns X[k] in xa and X[nc-k] in xb.
-__device__ __forceinline__ void real_split(const float2* z, int k, int nc, const float2* __restrict__ tw,
-                                           int tw_stride, float2& xa, float2& xb) {
-  const float2 a = z[k];
-  const float2 b = z[(nc - k) & (nc - 1)];
-  const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-  const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
-  const float2 O = make_float2(D.y, -D.x);  // -i * D
-  const float2 t = cmul(tw[k * tw_stride], O);
-  xa = make_float2(E.x + t.x, E.y + t.y);
-  xb = make_float2(E.x - t.x, -(E.y - t.y));
-}
+thread_local std::string g_hip_err;
 
 struct StftParams {
   const float* audio;
@@ -237,7 +117,6 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(StftParams p) {
 // Clamp against the per-clip max and apply the DCT-II matrix.  lane <-> frame so that both the
 // logmel reads [B][n_mels][T] and the MFCC writes [B][n_mfcc][T] are coalesced; the DCT row
 // index is wave-uniform, so the coefficients come through the scalar cache.
-#define MM_DCT_KB 16
 __global__ __launch_bounds__(256) void dct_clamp_kernel(const float* __restrict__ logmel,
                                                          const int* __restrict__ clip_key,
                                                          const float* __restrict__ dct_t /*[n_mels][KP]*/,
@@ -272,13 +151,6 @@ __global__ void decode_keys_kernel(int* inout, int64_t n) {
   if (i < n) reinterpret_cast<float*>(inout)[i] = key_float(inout[i]);
 }
 
-struct RfftParams {
-  const float* in;
-  int64_t rows, in_len, in_stride;
-  int n, log2nc, rows_per_wave;
-  const float2* tw;
-  float* out;  // complex64 [rows][n/2+1]
-};
 
 __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -311,132 +183,12 @@ __global__ __launch_bounds__(256) void rfft_generic_kernel(RfftParams p) {
 
 #include "mm_fft16.hip.inc"
 #include "mm_logmel16w.hip.inc"
-#include "mm_change.hip.inc"
-#include "mm_change_clip.hip.inc"
-#include "mm_sos_rows.hip.inc"
-#include "mm_logmel16s.hip.inc"
+#include "mm_s16.h"
 #include "mm_logmel12m.hip.inc"
 #include "mm_logmel16h.hip.inc"
 #include "mm_wpf.hip.inc"
-#include "mm_hilbert.hip.inc"
+#include "mm_hb_math.h"
 #include "mm_anyfft.hip.inc"
-#include "mm_resample.hip.inc"
-
-// ------------------------------------------------------------------------------------------
-// plan
-// ------------------------------------------------------------------------------------------
-#define MM_MAX_TIMED 16384
-#define MM_MAX_SAMPLES (((int64_t)1 << 29) - 8192)
-
-struct mm_plan {
-  mm_config cfg;
-  int device;
-  int n_bins, log2nc, kp;
-  float db_offset;
-  int path;           // 0 generic, 1 radix-16 register kernels
-  int force_generic;
-  float* d_window;
-  float2* d_tw;
-  int *d_mel_start, *d_mel_len, *d_mel_off;
-  float* d_mel_w;
-  float* d_dct_t;
-  float* d_sw_tab;             // mel run table of the fused kernel (headers + groups)
-  int* d_sw_part;
-  int sw_n_runs, sw_n_tab16;
-  size_t lm_lds_bytes;
-  float *d_w16_tab, *d_lane_tab;   // 16-wave variant: its own run table + per-lane records
-  int* d_w16_part;
-  int w16_n_runs, w16_n_tab16, w16_ok;
-  size_t w16_lds_bytes;
-  int s16_nr;                      // staged-sample variant: 16-byte groups per thread and tile (0: not usable)
-  size_t s16_lds_bytes;
-  // staged-sample variant with the (unclamped) DCT fused in: its own run table (four half-size parts for the
-  // DCT waves), DCT A operands, LDS layout
-  float *d_s16f_tab, *d_s16f_dcta;
-  int* d_s16f_part;
-  int s16f_ok, s16f_n_runs, s16f_n_tab16, s16f_lt_rows, s16f_nk, s16f_kb;
-  unsigned s16f_lt_off, s16f_dcta_off;
-  unsigned long long s16f_roles;
-  size_t s16f_lds_bytes;
-  // 12-wave MFMA-mel variant (mm_logmel12m.hip.inc)
-  float *d_m12_a, *d_m12_dct, *d_zeros;
-  int m12_units[MM_M12_MW * MM_M12_UMAX * 4], m12_nunits[8];
-  int m12_ok, m12_nb, m12_nstep8, m12_nr, m12_s_floats, m12_fused_dct;
-  unsigned m12_win_off, m12_tw_off, m12_a_off, m12_dct_off, m12_part_off, m12_cnt_off;
-  int m12_n_a2;
-  size_t m12_lds_bytes;
-  float* d_dctfm_a;                // dct_clamp_fm_mfma_kernel: A operands [kb][nk][64] (nullptr: VALU kernel)
-  int dctfm_nk, dctfm_kb;
-  size_t dctfm_lds;
-  float* d_dctw_a;                 // dct_clamp_fm_wave_kernel<CH>: the same, steps padded to a multiple of CH with zeros
-  int dctw_nk, dctw_ch;
-  int variant;                     // mm_plan_set_variant: 0 = automatic
-  int no_fuse;                     // mm_plan_set_fuse_dct(0): always run the separate clamp + DCT kernel
-  int no_fuse_tail;                // mm_plan_set_fuse_tail(0): mm_mfcc_modspec_f32 always runs its separate launches
-  unsigned s16f_red_off;           // clip mode: LDS offset of the per-wave clip max / min slots
-
-  float* d_window_e;                       // n_fft < 512 embedded in the 512-point kernels: window centred in 512
-  int embed;                               // 512 / n_fft for such plans, else 1
-  float *d_k2_lane_tab, *d_k2_mel_lane;   // wave-per-frame-group kernel (n_fft 512 / 1024 / 2048)
-  float* d_rf2k_lane_tab;                 // rfft_wpf_kernel<4> (stage-isolated rFFT, n = 2048)
-  int rf2k_ok;
-  int k2_ok, wpf_r, wpf_waves, wpf_group_max;
-  size_t wpf_lds_bytes;
-  int num_cus;
-  float* d_h16_tab; int* d_h16_part;       // 32-frame-tile / two-workgroup experiment (mm_logmel16h.hip.inc)
-  int h16_ok, h16_n_pairs, h16_n_tab16;
-  size_t h16_lds_bytes;
-  AnyPlan any;                             // any-length STFT (mm_anyfft.hip.inc): n_fft that is not a power of two in [32, 4096]
-  // timing
-  int timing_on;
-  std::vector<hipEvent_t> ev_pool;  // pairs
-  std::vector<int> ev_stage;
-  int ev_used;
-  double t_sum[MM_NUM_STAGES];
-  int64_t t_cnt[MM_NUM_STAGES];
-};
-
-namespace {
-
-struct StageTimer {
-  mm_plan* p;
-  hipStream_t s;
-  int idx;
-  StageTimer(mm_plan* plan, int stage, hipStream_t stream) : p(plan), s(stream), idx(-1) {
-    if (!p->timing_on || p->ev_used >= MM_MAX_TIMED) return;
-    if (p->timing_on != 1 && !((p->timing_on >> (stage + 1)) & 1)) return;   // stage mask
-    if ((size_t)(2 * p->ev_used + 1) >= p->ev_pool.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-      p->ev_pool.push_back(a);
-      p->ev_pool.push_back(b);
-    }
-    idx = p->ev_used++;
-    p->ev_stage.resize(p->ev_used);
-    p->ev_stage[idx] = stage;
-    (void)hipEventRecord(p->ev_pool[2 * idx], s);
-  }
-  ~StageTimer() {
-    if (idx >= 0) (void)hipEventRecord(p->ev_pool[2 * idx + 1], s);
-  }
-};
-
-int ilog2(int v) {
-  int l = 0;
-  while ((1 << l) < v) ++l;
-  return l;
-}
-
-template <class T>
-int upload(T** dst, const void* src, size_t bytes) {
-  HIP_TRY(hipMalloc((void**)dst, bytes));
-  HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-  return MM_OK;
-}
-
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-}  // namespace
 
 extern "C" {
 
@@ -1557,619 +1309,6 @@ int mm_plan_fused_tail(const mm_plan* p, int64_t batch, int64_t n_samples) {
   if (n_mod < 0) return 0;
   return (choose_kernel(p, 1, false, nullptr, 0, 0) == MM_K_W16S && n_samples >= 4 && p->s16f_ok && !p->no_fuse &&
           s16_clip_mode_ok(p, batch, n_mod)) ? 1 : 0;
-}
-
-// scipy.signal.sosfilt_zi + the padlen rule of sosfiltfilt, host side
-static int make_sosfilt(const double* sos, int n_sec, SosFilt* f) {
-  if (n_sec < 0 || n_sec > MM_MAX_SEC || (n_sec > 0 && !sos)) return MM_ERR_INVALID_ARG;
-  f->n_sec = n_sec;
-  f->padlen = 0;
-  if (n_sec == 0) return MM_OK;
-  double scale = 1.0;
-  int zb = 0, za = 0;
-  for (int s = 0; s < n_sec; ++s) {
-    const double* r = sos + 6 * s;
-    if (r[3] == 0.0) return MM_ERR_INVALID_ARG;
-    double b0 = r[0] / r[3], b1 = r[1] / r[3], b2 = r[2] / r[3], a1 = r[4] / r[3], a2 = r[5] / r[3];
-    f->c[s][0] = b0; f->c[s][1] = b1; f->c[s][2] = b2; f->c[s][3] = 1.0; f->c[s][4] = a1; f->c[s][5] = a2;
-    // lfilter_zi: (I - companion(a)^T) zi = b[1:] - a[1:] b0
-    const double B0 = b1 - a1 * b0, B1 = b2 - a2 * b0;
-    const double den = 1.0 + a1 + a2;
-    const double z0 = (B0 + B1) / den;
-    f->zi[s][0] = scale * z0;
-    f->zi[s][1] = scale * (B1 - a2 * z0);
-    scale *= (b0 + b1 + b2) / (1.0 + a1 + a2);
-    if (r[2] == 0.0) ++zb;
-    if (r[5] == 0.0) ++za;
-  }
-  const int ntaps = 2 * n_sec + 1 - (zb < za ? zb : za);
-  f->padlen = 3 * ntaps;
-  return MM_OK;
-}
-
-static int change_pads(int n_sec1, const double* sos1, int n_sec2, const double* sos2, SosFilt* f1, SosFilt* f2) {
-  int rc = make_sosfilt(sos1, n_sec1, f1);
-  if (rc) return rc;
-  if (n_sec1 < 1) return MM_ERR_INVALID_ARG;
-  return make_sosfilt(sos2, n_sec2, f2);
-}
-
-static int64_t round64(int64_t v) { return (v + 63) / 64 * 64; }
-
-// Upper bound over the three forms and every filter of up to MM_MAX_SEC sections (a caller that does not know its
-// filters yet); mm_change_workspace_bytes_for() sizes the form a given call takes.
-size_t mm_change_workspace_bytes(const mm_plan* p, int64_t batch, int64_t n_frames) {
-  if (!p || batch < 1 || n_frames < 1) return 0;
-  // two time-major buffers [T + 2 pad][columns padded to 64]; worst-case padding 3 * (2 * MM_MAX_SEC + 1)
-  const int64_t padmax = 3 * (2 * MM_MAX_SEC + 1);
-  const int64_t n = n_frames + 2 * padmax;
-  const size_t tm = (size_t)n * (size_t)(round64(batch * p->cfg.n_mfcc) + round64(batch));
-  // ... or the segmented rows' buffers (mm_sos_rows.hip.inc), whichever is larger
-  const int pads = 3 * (2 * MM_CLIP_NS + 1);
-  const size_t sg = chg_seg_workspace_doubles(batch, p->cfg.n_mfcc, n_frames, pads, pads);
-  return std::max(tm, sg) * sizeof(double);
-}
-
-// Which of the three device forms a change-tail call takes, and the workspace (in doubles) THAT form needs -- one
-// routine for the size query and for the call, so the two cannot disagree.
-enum { MM_CHG_TIME_MAJOR = 0, MM_CHG_CLIP = 1, MM_CHG_SEGMENTED = 2 };
-struct ChgForm { int form; size_t need; ClipShape cs; };
-static ChgForm change_form(const mm_plan* p, int64_t batch, int64_t n_frames, int n_rows, const SosFilt& f1, const SosFilt& f2) {
-  ChgForm r;
-  const int64_t p1 = f1.padlen, p2 = f2.n_sec > 0 ? f2.padlen : 0;
-  const int64_t n1 = n_frames + 2 * p1, n2 = n_frames + 2 * p2;
-  r.cs = clip_shape(n_rows, n1, n2);
-  const bool small_sec = f1.n_sec <= MM_CLIP_NS && f2.n_sec <= MM_CLIP_NS;
-  // Long clips (one recording at a 1 ms step is 10 001 frames per ten seconds): the clip form holds fewer and fewer rows
-  // at once and walks its groups one after the other -- from five groups on (about 5000 frames at 12 rows) a wave per
-  // 1088 samples of a row (mm_sos_rows.hip.inc) is faster at every clip count (tools/chg_forms.py: 8001 frames 0.80 ms
-  // against 0.11 - 0.45 ms for 1 - 256 clips; 4001 frames, three groups: 0.12 against 0.11 - 0.27 ms)
-  bool few_long = r.cs.G >= 1 && (n_rows + r.cs.G - 1) / r.cs.G > 4;
-#ifdef MM_DEV
-  if (const char* e = getenv("MM_CHG_FORM")) few_long = e[0] == 's';      // side build only: A/B of the two forms (tools/chg_forms.py)
-#endif
-  if (!p->no_fuse_tail && small_sec && (r.cs.G < 1 || few_long)) {
-    r.form = MM_CHG_SEGMENTED;
-    r.need = chg_seg_workspace_doubles(batch, n_rows, n_frames, (int)p1, (int)p2);
-  } else if (!p->no_fuse_tail && small_sec && r.cs.G >= 1) {
-    r.form = MM_CHG_CLIP;
-    r.need = (size_t)r.cs.tab_n;        // filter tables only (a few KB): the clip lives in LDS
-  } else {
-    r.form = MM_CHG_TIME_MAJOR;         // two time-major buffers [T + 2 pad][columns padded to 64]
-    r.need = (size_t)n1 * (size_t)round64(batch * n_rows) + (size_t)n2 * (size_t)round64(batch);
-  }
-  return r;
-}
-
-size_t mm_change_workspace_bytes_for(const mm_plan* p, int64_t batch, int64_t n_frames, int32_t remove_first, const double* sos1,
-                                     int32_t n_sec1, const double* sos2, int32_t n_sec2) {
-  if (!p || batch < 1 || n_frames < 1 || remove_first < 0 || remove_first >= p->cfg.n_mfcc) return 0;
-  SosFilt f1, f2;
-  if (change_pads(n_sec1, sos1, n_sec2, sos2, &f1, &f2)) return 0;
-  const int n_rows = p->cfg.n_mfcc - (remove_first ? 1 : 0);
-  return std::max<size_t>(change_form(p, batch, n_frames, n_rows, f1, f2).need, 1) * sizeof(double);
-}
-
-int mm_mfcc_change_f64(mm_plan* p, const float* d_mfcc, int64_t batch, int64_t n_frames,
-                       int32_t remove_first, int32_t diff_method, const double* sos1, int32_t n_sec1, const double* sos2,
-                       int32_t n_sec2, double* d_change, void* d_ws, size_t ws_bytes, void* stream) {
-  if (!p || !d_mfcc || !d_change || !d_ws || batch < 1 || n_frames < 1) return MM_ERR_INVALID_ARG;
-  if (diff_method < 0 || diff_method > 1 || (diff_method == 1 && n_frames < 3)) return MM_ERR_INVALID_ARG;
-  if (remove_first < 0 || remove_first >= p->cfg.n_mfcc) return MM_ERR_INVALID_ARG;
-  if (batch > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  SosFilt f1, f2;
-  int rc = change_pads(n_sec1, sos1, n_sec2, sos2, &f1, &f2);
-  if (rc) return rc;
-  // scipy: "The length of the input vector x must be greater than padlen"
-  if (n_frames <= f1.padlen || n_frames <= f2.padlen) return MM_ERR_INVALID_ARG;
-  ChangeParams q;
-  q.mfcc = d_mfcc; q.n_frames = n_frames; q.batch = batch; q.n_mfcc = p->cfg.n_mfcc;
-  q.first_row = remove_first ? 1 : 0; q.n_rows = q.n_mfcc - q.first_row;
-  q.p1 = f1.padlen; q.p2 = f2.n_sec > 0 ? f2.padlen : 0; q.sg = diff_method;
-  q.R = batch * q.n_rows; q.Rp = round64(q.R); q.Bp = round64(batch);
-  const int64_t n1 = n_frames + 2 * q.p1, n2 = n_frames + 2 * q.p2;
-  // the workspace of the form that runs (mm_change_workspace_bytes_for); mm_change_workspace_bytes is the bound over all forms
-  const ChgForm cf = change_form(p, batch, n_frames, q.n_rows, f1, f2);
-  if (ws_bytes < cf.need * sizeof(double)) return MM_ERR_WORKSPACE;
-  q.ws1 = (double*)d_ws; q.ws2 = q.ws1 + n1 * q.Rp; q.out = d_change;
-  const int64_t tblocks = (n_frames + 63) / 64;
-  if (tblocks > 65535 || 2 * (int64_t)q.p1 * q.Rp / 256 + 1 > 0x7FFFFFFF || n_frames * q.Bp / 256 + 1 > 0x7FFFFFFF ||
-      q.Bp / 64 > 65535 || n_frames > 0x7FFFFFFF)
-    return MM_ERR_INVALID_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  StageTimer tm(p, MM_STAGE_CHANGE, st);
-  if (cf.form == MM_CHG_SEGMENTED) {       // mm_sos_rows.hip.inc: a wave per 1088 samples of a row
-    rc = launch_chg_segmented(q, f1, f2, q.ws1, st);
-    if (rc) return rc;
-    HIP_TRY(hipGetLastError());
-    return MM_OK;
-  }
-  if (cf.form == MM_CHG_CLIP) {            // mm_change_clip.hip.inc: one launch, no workspace traffic
-    const ClipShape& cs = cf.cs;
-    const int ns = std::max(f1.n_sec, f2.n_sec);
-    rc = ns <= 2 ? launch_chg_clip<2>(q, f1, f2, cs, n1, n2, q.ws1, st)
-       : ns == 3 ? launch_chg_clip<3>(q, f1, f2, cs, n1, n2, q.ws1, st)
-                 : launch_chg_clip<4>(q, f1, f2, cs, n1, n2, q.ws1, st);
-    if (rc) return rc;
-    HIP_TRY(hipGetLastError());
-    return MM_OK;
-  }
-  hipLaunchKernelGGL(chg_pack_kernel, dim3((unsigned)(q.Rp / 64), (unsigned)tblocks), dim3(256), 0, st, q);
-  hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p1 * q.Rp + 255) / 256)), dim3(256), 0, st,
-                     q.ws1, n_frames, q.p1, q.Rp, 1);
-  launch_sos_any(f1, q.ws1, n1, q.Rp, st);
-  if (q.n_rows <= MM_CHG_MAXROWS)
-    hipLaunchKernelGGL(chg_norm_kernel, dim3((unsigned)n_frames, (unsigned)(q.Bp / 64)), dim3(256), 0, st, q);
-  else
-    hipLaunchKernelGGL(chg_norm_rows_kernel, dim3((unsigned)((n_frames * q.Bp + 255) / 256)), dim3(256), 0, st, q);
-  if (f2.n_sec > 0) {
-    hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)q.p2 * q.Bp + 255) / 256)), dim3(256), 0, st,
-                       q.ws2, n_frames, q.p2, q.Bp, 0);
-    launch_sos_any(f2, q.ws2, n2, q.Bp, st);
-  }
-  hipLaunchKernelGGL(chg_unpack_kernel, dim3((unsigned)(q.Bp / 64), (unsigned)tblocks), dim3(256), 0, st, q);
-  HIP_TRY(hipGetLastError());
-  return MM_OK;
-}
-
-size_t mm_sosfiltfilt_workspace_bytes(int64_t rows, int64_t n) {
-  if (rows < 1 || n < 1) return 0;
-  // the larger of the two device forms: time-major [n + 2 pad][rows padded to 64] | segmented rows (mm_sos_rows.hip.inc)
-  const size_t tm = (size_t)(n + 2 * 3 * (2 * MM_MAX_SEC + 1)) * (size_t)round64(rows);
-  const size_t sg = seg_workspace_doubles(rows, n, 3 * (2 * MM_CLIP_NS + 1));
-  return std::max(tm, sg) * sizeof(double);
-}
-
-// d_x (float64 rows) or d_xf (float32 rows: odd extension in float32 arithmetic, see odd_ext_f32)
-static int sosfiltfilt_impl(const double* d_x, const float* d_xf, int64_t rows, int64_t n, int64_t x_stride, const double* sos,
-                            int32_t n_sec, double* d_y, void* d_ws, size_t ws_bytes, void* stream) {
-  if ((!d_x && !d_xf) || !d_y || !d_ws || rows < 1 || n < 1 || x_stride < n || n_sec < 1) return MM_ERR_INVALID_ARG;
-  SosFilt f;
-  int rc = make_sosfilt(sos, n_sec, &f);
-  if (rc) return rc;
-  if (n <= f.padlen) return MM_ERR_INVALID_ARG;      // scipy: "The length of the input vector x must be greater than padlen"
-  if (ws_bytes < mm_sosfiltfilt_workspace_bytes(rows, n)) return MM_ERR_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  if (f.n_sec <= MM_CLIP_NS) {     // segmented rows: a wave per 1088 samples of a row, any length
-    const SegSrc src = {d_x, x_stride, d_xf, 0, 0, 0};
-    rc = launch_sos_rows_any(f, src, rows, n, d_y, (double*)d_ws, st);
-    if (rc) return rc;
-    HIP_TRY(hipGetLastError());
-    return MM_OK;
-  }
-  const int64_t Wp = round64(rows), tb = (n + 63) / 64;
-  if (tb > 65535 || Wp / 64 > 0x7FFFFFFF || 2 * (int64_t)f.padlen * Wp / 256 + 1 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  double* ws = (double*)d_ws;
-  if (d_xf)
-    hipLaunchKernelGGL((sos_rows_pack_kernel<float>), dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, d_xf, rows, n,
-                       x_stride, f.padlen, Wp, ws);
-  else
-    hipLaunchKernelGGL((sos_rows_pack_kernel<double>), dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, d_x, rows, n,
-                       x_stride, f.padlen, Wp, ws);
-  hipLaunchKernelGGL(chg_pad_kernel, dim3((unsigned)((2 * (int64_t)f.padlen * Wp + 255) / 256)), dim3(256), 0, st, ws, n,
-                     f.padlen, Wp, d_xf ? 1 : 0);
-  launch_sos_any(f, ws, n + 2 * f.padlen, Wp, st);
-  hipLaunchKernelGGL(sos_rows_unpack_kernel, dim3((unsigned)(Wp / 64), (unsigned)tb), dim3(256), 0, st, ws, rows, n, f.padlen,
-                     Wp, d_y);
-  HIP_TRY(hipGetLastError());
-  return MM_OK;
-}
-
-int mm_sosfiltfilt_f64(const double* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos, int32_t n_sec,
-                       double* d_y, void* d_ws, size_t ws_bytes, void* stream) {
-  if (!d_x) return MM_ERR_INVALID_ARG;
-  return sosfiltfilt_impl(d_x, nullptr, rows, n, x_stride, sos, n_sec, d_y, d_ws, ws_bytes, stream);
-}
-
-int mm_sosfiltfilt_f32_f64(const float* d_x, int64_t rows, int64_t n, int64_t x_stride, const double* sos, int32_t n_sec,
-                           double* d_y, void* d_ws, size_t ws_bytes, void* stream) {
-  if (!d_x) return MM_ERR_INVALID_ARG;
-  return sosfiltfilt_impl(nullptr, d_x, rows, n, x_stride, sos, n_sec, d_y, d_ws, ws_bytes, stream);
-}
-
-int mm_stencil_f64(const mm_stencil* st, const double* d_x, int64_t rows, int64_t n, int64_t x_stride, double* d_y,
-                   void* stream) {
-  if (!st || !d_x || !d_y || rows < 1 || n < 1 || x_stride < n) return MM_ERR_INVALID_ARG;
-  if (st->n_c < 1 || st->n_c > MM_ST_MAXW || st->n_edge < 0 || st->n_edge > MM_ST_MAXE || st->edge_w < 0 ||
-      st->edge_w > MM_ST_MAXW || (st->n_edge > 0 && st->edge_w < 1) || st->den_c == 0.0 ||
-      (st->n_edge > 0 && st->den_e == 0.0))
-    return MM_ERR_INVALID_ARG;
-  int lo = 0, hi = 0;
-  for (int k = 0; k < st->n_c; ++k) { lo = std::min(lo, st->off[k]); hi = std::max(hi, st->off[k]); }
-  // every interior output must find its taps inside the row, the edge rows their inputs
-  if (n < 2 * (int64_t)st->n_edge || n < st->edge_w || -lo > st->n_edge || hi > st->n_edge) return MM_ERR_INVALID_ARG;
-  const int64_t total = rows * n;
-  if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(stencil_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *st, d_x,
-                     rows, n, x_stride, d_y);
-  HIP_TRY(hipGetLastError());
-  return MM_OK;
-}
-
-// one wave per output frame: coalesced strided sum of squares, zero padding outside the clip
-__global__ __launch_bounds__(256) void rms_frames_kernel(const float* __restrict__ audio, int64_t n_samples,
-                                                         int64_t stride, int frame_length, int hop, int pad,
-                                                         int64_t n_out, int64_t total, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= total) return;
-  const int64_t b = w / n_out, t = w - b * n_out;
-  const float* a = audio + b * stride;
-  const int64_t start = t * hop - pad;
-  float acc = 0.0f;
-  for (int j = lane; j < frame_length; j += 64) {
-    const int64_t i = start + j;
-    const float v = (i >= 0 && i < n_samples) ? a[i] : 0.0f;
-    acc = fmaf(v, v, acc);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) out[w] = sqrtf(acc / (float)frame_length);
-}
-
-// Tiled variant: a workgroup squares the (F-1)*hop + frame_length samples of F consecutive frames of
-// one clip into LDS once (frames overlap frame_length/hop times), then every wave sums whole frames
-// from LDS in the same order as rms_frames_kernel (lane-strided, then a butterfly): same bits, each
-// sample read from global memory ~once instead of frame_length/hop times.
-__global__ __launch_bounds__(256) void rms_tile_kernel(const float* __restrict__ audio, int64_t n_samples,
-                                                       int64_t stride, int frame_length, int hop, int pad,
-                                                       int64_t n_out, int frames_per_tile, int64_t tiles_per_clip,
-                                                       float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float rms_sq[];
-  float* sq = rms_sq;
-  const int64_t b = blockIdx.x / tiles_per_clip, tile = blockIdx.x - b * tiles_per_clip;
-  const int64_t t0 = tile * frames_per_tile;
-  const int nf = (int)((n_out - t0) < frames_per_tile ? (n_out - t0) : frames_per_tile);
-  const int span = (nf - 1) * hop + frame_length;
-  const float* a = audio + b * stride;
-  const int64_t start = t0 * hop - pad;
-  for (int j0 = threadIdx.x; j0 < span; j0 += 1024) {   // four independent loads in flight per thread
-    float v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t i = start + j0 + 256 * u;
-      v[u] = (i >= 0 && i < n_samples && j0 + 256 * u < span) ? a[i] : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (j0 + 256 * u < span) sq[j0 + 256 * u] = v[u] * v[u];
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int f = wave; f < nf; f += 4) {
-    const float* s = sq + f * hop;
-    float acc = 0.0f;
-    for (int j = lane; j < frame_length; j += 64) acc += s[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) out[b * n_out + t0 + f] = sqrtf(acc / (float)frame_length);
-  }
-}
-
-int64_t mm_rms_num_frames(int64_t n_samples, int32_t frame_length, int32_t hop_length, int32_t center) {
-  if (n_samples < 1 || frame_length < 1 || hop_length < 1) return MM_ERR_INVALID_ARG;
-  const int64_t padded = n_samples + (center ? 2 * (int64_t)(frame_length / 2) : 0);
-  if (padded < frame_length) return MM_ERR_INVALID_ARG;
-  return 1 + (padded - frame_length) / hop_length;
-}
-
-int mm_rms_f32(const float* d_audio, int64_t batch, int64_t n_samples, int64_t stride, int32_t frame_length,
-               int32_t hop_length, int32_t center, float* d_rms, void* stream) {
-  if (!d_audio || !d_rms || batch < 1 || stride < n_samples) return MM_ERR_INVALID_ARG;
-  const int64_t n_out = mm_rms_num_frames(n_samples, frame_length, hop_length, center);
-  if (n_out < 0) return (int)n_out;
-  const int64_t total = batch * n_out;
-  // tiled kernel: ~16 frames per workgroup (small tiles keep many workgroups per CU in flight), LDS
-  // between 16 and 64 KB
-  int64_t want = (int64_t)frame_length + 15 * (int64_t)hop_length;
-  const int lds_floats = (int)(want < 4096 ? 4096 : (want > 16384 ? 16384 : want));
-  if (frame_length <= lds_floats) {
-    int64_t fpt = (lds_floats - frame_length) / hop_length + 1;
-    if (fpt > 64) fpt = 64;
-    if (fpt > n_out) fpt = n_out;
-    const int64_t tpc = (n_out + fpt - 1) / fpt;
-    if (batch * tpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-    const size_t lds = (size_t)((fpt - 1) * hop_length + frame_length) * 4;
-    hipLaunchKernelGGL(rms_tile_kernel, dim3((unsigned)(batch * tpc)), dim3(256), lds, (hipStream_t)stream, d_audio,
-                       n_samples, stride, frame_length, hop_length, center ? frame_length / 2 : 0, n_out, (int)fpt, tpc,
-                       d_rms);
-    HIP_TRY(hipGetLastError());
-    return MM_OK;
-  }
-  const int64_t grid = (total + 3) / 4;
-  if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(rms_frames_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_audio,
-                     n_samples, stride, frame_length, hop_length, center ? frame_length / 2 : 0, n_out, total, d_rms);
-  HIP_TRY(hipGetLastError());
-  return MM_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// Input side: what librosa.load(path, sr=sigSr, mono=False) does before the hot
-// path (script/mfcc.py:284,373) -- PCM decode to float32 in [-1, 1) and sample-rate conversion.
-// ------------------------------------------------------------------------------------------
-// interleaved PCM frames -> planar float32 [channels][n]; fmt: 1 = u8, 2 = s16, 3 = s24 (packed), 4 = s32,
-// 5 = f32, 6 = f64 (little endian; scaling as libsndfile / soundfile: s16 / 32768, s24 / 2^23, s32 / 2^31,
-// u8 (x - 128) / 128)
-__global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char* __restrict__ raw, int fmt, int channels,
-                                                         int64_t n, float* __restrict__ out, int64_t out_stride) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * channels) return;
-  const int64_t fr = idx / channels;
-  const int ch = (int)(idx - fr * channels);
-  float v;
-  switch (fmt) {
-    case 1: v = ((float)raw[idx] - 128.0f) * (1.0f / 128.0f); break;
-    case 2: { const short q = (short)((unsigned)raw[2 * idx] | ((unsigned)raw[2 * idx + 1] << 8)); v = (float)q * (1.0f / 32768.0f); break; }
-    case 3: { int q = (int)((unsigned)raw[3 * idx] | ((unsigned)raw[3 * idx + 1] << 8) | ((unsigned)raw[3 * idx + 2] << 16));
-              q = (q << 8) >> 8; v = (float)q * (1.0f / 8388608.0f); break; }
-    case 4: { const int q = (int)((unsigned)raw[4 * idx] | ((unsigned)raw[4 * idx + 1] << 8) | ((unsigned)raw[4 * idx + 2] << 16) |
-                                  ((unsigned)raw[4 * idx + 3] << 24));
-              v = (float)((double)q * (1.0 / 2147483648.0)); break; }
-    case 5: { unsigned u = (unsigned)raw[4 * idx] | ((unsigned)raw[4 * idx + 1] << 8) | ((unsigned)raw[4 * idx + 2] << 16) |
-                           ((unsigned)raw[4 * idx + 3] << 24);
-              v = __uint_as_float(u); break; }
-    default: { unsigned long long u = 0;
-               for (int b = 0; b < 8; ++b) u |= (unsigned long long)raw[8 * idx + b] << (8 * b);
-               v = (float)__longlong_as_double((long long)u); break; }
-  }
-  out[(int64_t)ch * out_stride + fr] = v;
-}
-
-// 16-bit PCM, mono or stereo (what almost every WAVE file is): a thread takes 16 bytes = 8 samples with ONE load and
-// stores whole float4s per channel -- the byte-wise kernel above issues two 1-byte loads and one 4-byte store per sample
-// (0.59 ms for 256 stereo clips x 10 s x 44.1 kHz = 2.3 TB/s of bytes read + written).  Same arithmetic (q / 32768).
-extern "C++" {
-template <int CH>
-__global__ __launch_bounds__(256) void pcm_decode_s16_kernel(const uint4* __restrict__ raw, int64_t n_vec, float* __restrict__ out,
-                                                             int64_t out_stride) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += stride) {
-    const uint4 w = raw[v];
-    const unsigned u[4] = {w.x, w.y, w.z, w.w};
-    float f[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f[2 * i] = (float)(short)(u[i] & 0xFFFFu) * (1.0f / 32768.0f);
-      f[2 * i + 1] = (float)(short)(u[i] >> 16) * (1.0f / 32768.0f);
-    }
-    if (CH == 1) {
-      float4* o = reinterpret_cast<float4*>(out + 8 * v);
-      o[0] = make_float4(f[0], f[1], f[2], f[3]);
-      o[1] = make_float4(f[4], f[5], f[6], f[7]);
-    } else {
-      *reinterpret_cast<float4*>(out + 4 * v) = make_float4(f[0], f[2], f[4], f[6]);
-      *reinterpret_cast<float4*>(out + out_stride + 4 * v) = make_float4(f[1], f[3], f[5], f[7]);
-    }
-  }
-}
-// 32-bit float data, mono or stereo: 32 bytes (two 16-byte loads) per thread, 16-byte stores per channel
-template <int CH>
-__global__ __launch_bounds__(256) void pcm_decode_f32_kernel(const float4* __restrict__ raw, int64_t n_vec, float* __restrict__ out,
-                                                             int64_t out_stride) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += stride) {
-    const float4 a = raw[2 * v], b = raw[2 * v + 1];
-    if (CH == 1) {
-      float4* o = reinterpret_cast<float4*>(out + 8 * v);
-      o[0] = a; o[1] = b;
-    } else {
-      *reinterpret_cast<float4*>(out + 4 * v) = make_float4(a.x, a.z, b.x, b.z);
-      *reinterpret_cast<float4*>(out + out_stride + 4 * v) = make_float4(a.y, a.w, b.y, b.w);
-    }
-  }
-}
-}  // extern "C++"
-
-int mm_pcm_decode_f32(const void* d_raw, int32_t fmt, int32_t channels, int64_t n_frames, float* d_out, int64_t out_stride,
-                      void* stream) {
-  if (!d_raw || !d_out || fmt < 1 || fmt > 6 || channels < 1 || n_frames < 1 || out_stride < n_frames) return MM_ERR_INVALID_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  int64_t done = 0;                                      // frames taken by the vector kernel
-  if ((fmt == 2 || fmt == 5) && (channels == 1 || channels == 2) && (((uintptr_t)d_raw | (uintptr_t)d_out) & 15) == 0 &&
-      (channels == 1 || (out_stride & 3) == 0)) {
-    const int64_t fpv = 8 / channels, n_vec = n_frames / fpv;      // a thread takes 8 samples (16 / 32 bytes)
-    if (n_vec > 0) {
-      const dim3 gd((unsigned)std::min<int64_t>((n_vec + 255) / 256, 256 * 16)), bd(256);
-      if (fmt == 2) {
-        if (channels == 1) hipLaunchKernelGGL(pcm_decode_s16_kernel<1>, gd, bd, 0, st, (const uint4*)d_raw, n_vec, d_out, out_stride);
-        else hipLaunchKernelGGL(pcm_decode_s16_kernel<2>, gd, bd, 0, st, (const uint4*)d_raw, n_vec, d_out, out_stride);
-      } else {
-        if (channels == 1) hipLaunchKernelGGL(pcm_decode_f32_kernel<1>, gd, bd, 0, st, (const float4*)d_raw, n_vec, d_out, out_stride);
-        else hipLaunchKernelGGL(pcm_decode_f32_kernel<2>, gd, bd, 0, st, (const float4*)d_raw, n_vec, d_out, out_stride);
-      }
-      done = n_vec * fpv;
-    }
-  }
-  const int64_t rest = n_frames - done;
-  if (rest > 0) {
-    const int64_t total = rest * channels;
-    if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-    const int bps = fmt == 1 ? 1 : fmt == 2 ? 2 : fmt == 3 ? 3 : fmt == 6 ? 8 : 4;
-    hipLaunchKernelGGL(pcm_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       (const unsigned char*)d_raw + done * channels * bps, fmt, channels, rest, d_out + done, out_stride);
-  }
-  HIP_TRY(hipGetLastError());
-  return MM_OK;
-}
-
-// Rational-ratio polyphase FIR sample-rate conversion: output m = sum_j h[ph + j L] x[ih - j] with t = m M + c,
-// ih = t div L, ph = t mod L, zero signal outside the clip -- upfirdn with the filter delay c removed, n_out =
-// ceil(n L / M) (what scipy.signal.resample_poly and librosa.resample return); float64 accumulation.
-// A thread computes MM_RS_P outputs of ONE phase (m, m + F, m + 2F, ..., F a multiple of L), so a tap is fetched
-// once for all of them, and the taps come in OUTPUT-phase order in records of four, hq4[j / 4][t][j % 4] = h[ph_t +
-// j L] with ph_t = (t M + c) mod L for the output index t within a period: adjacent threads = adjacent outputs read
-// adjacent 16-byte records, their input samples lie within a few cache lines of each other and are fetched four at
-// a time (16-byte loads at 4-byte aligned addresses).  (The first version -- one
-// thread per output, taps in polyphase order [L][tpp], i.e. a 2 KB stride between lanes -- ran at 0.3 T
-// multiply-adds per second: 66 ms for 256 ten-second clips 44.1 -> 16 kHz.)
-#define MM_RS_P 4
-struct __attribute__((packed, aligned(4))) MmRsFloat4U { float x, y, z, w; };
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int64_t n_in, int64_t in_stride,
-                                                       const float* __restrict__ hq, int L, int M, int tpp4, int64_t c,
-                                                       int64_t n_out, int64_t F, float* __restrict__ y) {
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (f >= F) return;
-  const int64_t r = blockIdx.y;
-  const float* xr = x + r * in_stride;
-  const int t = (int)(f % L);
-  const int64_t t0 = f * M + c;                   // F is a multiple of L: output f + i F has the phase of output f
-  const int64_t ih0 = t0 / L, step = (F / L) * M;
-  double acc[MM_RS_P];
-  int64_t ih[MM_RS_P];
-#pragma unroll
-  for (int i = 0; i < MM_RS_P; ++i) { acc[i] = 0.0; ih[i] = ih0 + i * step; }
-  // taps of this output phase, four consecutive j per 16-byte record: record j4 at hq4[j4 * L + t]
-  const float4* h4 = reinterpret_cast<const float4*>(hq) + t;
-  const float* h1 = hq + 4 * (int64_t)t;
-  const int tpp = 4 * tpp4;
-  // taps j for which EVERY one of the thread's outputs reads inside the clip: no checks there, whole records only
-  int64_t jlo = 0, jhi = tpp;
-#pragma unroll
-  for (int i = 0; i < MM_RS_P; ++i) {
-    const int64_t lo = ih[i] - (n_in - 1), hi = ih[i] + 1;      // valid j: lo <= j < hi
-    jlo = lo > jlo ? lo : jlo;
-    jhi = hi < jhi ? hi : jhi;
-  }
-  jlo = (jlo + 3) / 4 * 4;
-  jhi = jhi / 4 * 4;
-  if (jlo > tpp) jlo = tpp;
-  if (jhi < jlo) jhi = jlo;
-  auto checked = [&](int64_t ja, int64_t jb) {
-    for (int64_t j = ja; j < jb; ++j) {
-      const double tap = (double)h1[(j >> 2) * 4 * L + (j & 3)];
-#pragma unroll
-      for (int i = 0; i < MM_RS_P; ++i) {
-        const int64_t idx = ih[i] - j;
-        if (idx >= 0 && idx < n_in) acc[i] = fma(tap, (double)xr[idx], acc[i]);
-      }
-    }
-  };
-  checked(0, jlo);
-#pragma unroll 2
-  for (int64_t j = jlo; j < jhi; j += 4) {
-    const float4 tp = h4[(j >> 2) * L];
-#pragma unroll
-    for (int i = 0; i < MM_RS_P; ++i) {
-      // x[ih - j - 3 .. ih - j]: one 16-byte load at a 4-byte aligned address
-      const MmRsFloat4U xv = *reinterpret_cast<const MmRsFloat4U*>(xr + (ih[i] - j - 3));
-      acc[i] = fma((double)tp.x, (double)xv.w, acc[i]);
-      acc[i] = fma((double)tp.y, (double)xv.z, acc[i]);
-      acc[i] = fma((double)tp.z, (double)xv.y, acc[i]);
-      acc[i] = fma((double)tp.w, (double)xv.x, acc[i]);
-    }
-  }
-  checked(jhi, tpp);
-#pragma unroll
-  for (int i = 0; i < MM_RS_P; ++i) {
-    const int64_t m = f + i * F;
-    if (m < n_out) y[r * n_out + m] = (float)acc[i];
-  }
-}
-
-int mm_resample_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_taps, int32_t L, int32_t M,
-                    int32_t taps_per_phase, int64_t half_len, float* d_y, int64_t n_out, void* stream) {
-  if (!d_x || !d_taps || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || L < 1 || M < 1 || taps_per_phase < 4 ||
-      (taps_per_phase & 3) || half_len < 0 || n_out < 1 || rows > 65535 || (((uintptr_t)d_taps) & 15))
-    return MM_ERR_INVALID_ARG;
-  if (n_out != (n_in * L + M - 1) / M) return MM_ERR_INVALID_ARG;
-  // threads per row: ceil(n_out / P) rounded up to a multiple of L
-  const int64_t per = (n_out + MM_RS_P - 1) / MM_RS_P;
-  const int64_t F = (per + L - 1) / L * L;
-  if ((F + 255) / 256 > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream, d_x,
-                     n_in, x_stride, d_taps, L, M, taps_per_phase / 4, half_len, n_out, F, d_y);
-  HIP_TRY(hipGetLastError());
-  return MM_OK;
-}
-
-// The same conversion as a banded GEMM on the matrix pipe (mm_resample.hip.inc).  The host lays the taps out as MFMA A
-// operands (modulation_mfcc_amd/audio_io.py: banded_tables): d_atab [NB][ksteps][64] floats, d_lo_off [NB] int32;
-// F = c L >= 16 outputs per period (the host picks the smallest multiple of L that wastes <= 13 % of its last block of 16),
-// S = F M / L input samples per period, lo_min = first input sample (relative to a
-// period's origin, may be negative) of the first block's window, win = floats of one period's window union.
-int mm_resample_banded_f32(const float* d_x, int64_t rows, int64_t n_in, int64_t x_stride, const float* d_atab,
-                           const int32_t* d_lo_off, int32_t F, int32_t S, int32_t NB, int32_t ksteps, int32_t lo_min,
-                           int32_t win, float* d_y, int64_t n_out, void* stream) {
-  if (!d_x || !d_atab || !d_lo_off || !d_y || rows < 1 || n_in < 1 || x_stride < n_in || F < 16 || S < 1 ||
-      NB != (F + 15) / 16 || ksteps < 8 || (ksteps & 7) || win < 4 * ksteps || n_out < 1 || (((uintptr_t)d_atab) & 15))
-    return MM_ERR_INVALID_ARG;
-  // bank pattern of one ds_read_b32: lanes (k = 0, 1) x (q = 0 .. 15) read words q S + k -- pad the tile when more than
-  // two of them share a bank
-  int cnt[32] = {0}, worst = 0;
-  for (int k = 0; k < 2; ++k)
-    for (int q = 0; q < 16; ++q) worst = std::max(worst, ++cnt[(int)(((int64_t)q * S + k) & 31)]);
-  const bool pad = worst > 2;
-  auto tile_bytes = [&](int qt) {
-    const int64_t fl = (int64_t)(16 * qt - 1) * S + win + 8;        // + the alignment shift and the last 16-byte vector
-    return (size_t)(pad ? fl + (fl >> 5) + 1 : fl) * 4;
-  };
-  // periods per tile = 16 QT: the largest tile of which two fit a CU (two workgroups: one stages while the other
-  // multiplies) -- ratios with few blocks per period (1 / 3: NB = 1) get their units from more period tiles
-#ifndef MM_RSM_TILE_KB
-#define MM_RSM_TILE_KB 80
-#endif
-#ifndef MM_RSM_WG_PER_CU
-#define MM_RSM_WG_PER_CU 4          // small tiles (1 / 3, 2 / 1 ...): four workgroups per CU, 0.76 -> 0.67 ms at 48 -> 16 kHz
-#endif
-  int QT = 8;
-  while (QT > 1 && tile_bytes(QT) > MM_RSM_TILE_KB * 1024) QT >>= 1;
-  if (tile_bytes(QT) > MM_LM_LDS_MAX) return MM_ERR_UNSUPPORTED;     // (the caller falls back to mm_resample_f32)
-  RsmParams q;
-  q.x = d_x; q.rows = rows; q.n_in = n_in; q.x_stride = x_stride; q.atab = d_atab; q.lo_off = d_lo_off;
-  q.F = F; q.S = S; q.NB = NB; q.ksteps = ksteps; q.lo_min = lo_min; q.QT = QT;
-  q.tile_floats = (int)((int64_t)(16 * QT - 1) * S + win);
-  q.y = d_y; q.n_out = n_out;
-  const int64_t periods = (n_out + F - 1) / F;
-  q.tiles_per_row = (periods + 16 * QT - 1) / (16 * QT);
-  q.n_items = rows * q.tiles_per_row;
-  static PerDeviceOnce attr_once;
-  {
-    const int rc = per_device_once(attr_once, "resample_mfma_kernel", [] {
-      const void* kf[4] = {(const void*)resample_mfma_kernel<false, false>, (const void*)resample_mfma_kernel<false, true>,
-                           (const void*)resample_mfma_kernel<true, false>, (const void*)resample_mfma_kernel<true, true>};
-      for (int i = 0; i < 4; ++i)
-        if (hipFuncSetAttribute(kf[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) return false;
-      return true;
-    });
-    if (rc) return rc;
-  }
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
-  const size_t lds = tile_bytes(QT);
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(MM_RSM_WG_PER_CU, (size_t)MM_LM_LDS_MAX / lds));
-  const int64_t grid = std::min<int64_t>(q.n_items, (int64_t)per_cu * cus);
-  const bool vec = (((uintptr_t)d_x) & 15) == 0 && (x_stride & 3) == 0;
-  const dim3 gd((unsigned)grid), bd(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (pad) { if (vec) hipLaunchKernelGGL((resample_mfma_kernel<true, true>), gd, bd, lds, st, q); else hipLaunchKernelGGL((resample_mfma_kernel<true, false>), gd, bd, lds, st, q); }
-  else { if (vec) hipLaunchKernelGGL((resample_mfma_kernel<false, true>), gd, bd, lds, st, q); else hipLaunchKernelGGL((resample_mfma_kernel<false, false>), gd, bd, lds, st, q); }
-  HIP_TRY(hipGetLastError());
-  return MM_OK;
-}
-
-// Measurement aid (bench.py): float4 grid-stride device-to-device copy on the caller's stream -- the
-// practical HBM ceiling the stage-isolated rFFT figure is compared with (MI355X_MICROARCH.md quotes
-// 6.29 TB/s for this shape of kernel).  n_floats must be a multiple of 4, pointers 16-byte aligned.
-__global__ __launch_bounds__(256) void devcopy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
-  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
-  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (i + 256 * u < n4) v[u] = src[i + 256 * u];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (i + 256 * u < n4) dst[i + 256 * u] = v[u];
-  }
-}
-
-int mm_devcopy_f32(const float* d_src, float* d_dst, int64_t n_floats, void* stream) {
-  if (!d_src || !d_dst || n_floats < 4 || (n_floats & 3) || (((uintptr_t)d_src | (uintptr_t)d_dst) & 15)) return MM_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(devcopy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)d_src, (float4*)d_dst,
-                     n_floats / 4);
-  HIP_TRY(hipGetLastError());
-  return MM_OK;
 }
 
 int mm_timing_enable(mm_plan* p, int on) {

@@ -1,0 +1,166 @@
+// Shared by every translation unit of libmodmfcc.so: includes, the error string, HIP_TRY, per-device attribute flags,
+// small device helpers.  gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <atomic>
+#include <new>
+
+#include "mm_internal.h"
+#include "mm_dev.h"
+
+#define MM_TW_N 8192  // master twiddle table: exp(-2 pi i k / 8192), k < 8192 (full circle)
+
+extern thread_local std::string g_hip_err;      // defined in mm_api.hip; mm_last_hip_error() returns it
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);          \
+      return MM_ERR_HIP;                                                      \
+    }                                                                         \
+  } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the device function object, i.e. it is kept PER DEVICE: the
+// entry points that have no plan to set it in (mm_mfcc_change_f64, mm_sosfiltfilt_*, mm_resample_banded_f32 take any
+// stream of any device) set it once per device, behind a flag indexed by hipGetDevice() -- atomic, so that two host
+// threads making their first calls at once are fine (both may set the attribute: idempotent).
+#define MM_MAX_DEV 64
+struct PerDeviceOnce { std::atomic<int> done[MM_MAX_DEV]; };
+template <class F>
+static int per_device_once(PerDeviceOnce& o, const char* what, F set) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { g_hip_err = "hipGetDevice failed"; return MM_ERR_HIP; }
+  const bool flagged = dev >= 0 && dev < MM_MAX_DEV;
+  if (flagged && o.done[dev].load(std::memory_order_acquire)) return MM_OK;
+  if (!set()) { g_hip_err = std::string("hipFuncSetAttribute(") + what + ") failed"; return MM_ERR_HIP; }
+  if (flagged) o.done[dev].store(1, std::memory_order_release);
+  return MM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of ONE wave execute in order; this only stops the compiler from moving
+  // accesses across the point where lanes exchange data through the wave-private buffer.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every
+// global load / store / atomic in flight: in the persistent fused kernels that exposes a full
+// memory round trip per tile (the next tile's prefetch before phase B, the log-mel stores after it).
+__device__ __forceinline__ void wg_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// order-preserving float -> int key for atomicMax
+__device__ __forceinline__ int float_key(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float key_float(int k) {
+  return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+typedef float mm_f32x4 __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f32_16x16x4_f32
+
+// In-place radix-2 DIT over a wave-private LDS buffer; input already bit-reversed.
+__device__ __forceinline__ void wave_cfft_lds(float2* z, int log2nc, const float2* __restrict__ tw,
+                                              int lane) {
+  const int nc = 1 << log2nc;
+  for (int s = 1; s <= log2nc; ++s) {
+    const int half = 1 << (s - 1);
+    const int tw_stride = MM_TW_N >> s;
+    for (int j = lane; j < (nc >> 1); j += 64) {
+      const int pos = j & (half - 1);
+      const int i0 = ((j >> (s - 1)) << s) + pos;
+      const int i1 = i0 + half;
+      const float2 w = tw[pos * tw_stride];
+      const float2 a = z[i0];
+      const float2 t = cmul(w, z[i1]);
+      z[i0] = make_float2(a.x + t.x, a.y + t.y);
+      z[i1] = make_float2(a.x - t.x, a.y - t.y);
+    }
+    wave_lds_sync();
+  }
+}
+
+// Split the half-length complex FFT Z (nc points, in LDS) of a packed real row into the real
+// FFT bins k and nc-k.  Returns X[k] in xa and X[nc-k] in xb.
+__device__ __forceinline__ void real_split(const float2* z, int k, int nc, const float2* __restrict__ tw,
+                                           int tw_stride, float2& xa, float2& xb) {
+  const float2 a = z[k];
+  const float2 b = z[(nc - k) & (nc - 1)];
+  const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+  const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+  const float2 O = make_float2(D.y, -D.x);  // -i * D
+  const float2 t = cmul(tw[k * tw_stride], O);
+  xa = make_float2(E.x + t.x, E.y + t.y);
+  xb = make_float2(E.x - t.x, -(E.y - t.y));
+}
+
+// native vector types and explicit address spaces (1 = global, 3 = LDS) for code that must not fall back to flat accesses
+typedef float mm_v2f __attribute__((ext_vector_type(2)));
+typedef float mm_v4f __attribute__((ext_vector_type(4)));
+#define MM_GLOBAL __attribute__((address_space(1)))
+#define MM_LDS __attribute__((address_space(3)))
+
+typedef unsigned mm_v2u __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) MmFloat4U { float x, y, z, w; };
+
+#define MM_LM_LDS_MAX 163840     // the CU's whole LDS: what a single workgroup may declare (160 KiB)
+#define MM_DCT_KB 16            // DCT coefficients per accumulator block of the lane <-> frame clamp + DCT kernels
+
+struct RfftParams {
+  const float* in;
+  int64_t rows, in_len, in_stride;
+  int n, log2nc, rows_per_wave;
+  const float2* tw;
+  float* out;  // complex64 [rows][n/2+1]
+};
+
+namespace {
+
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+template <class T>
+int upload(T** dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMalloc((void**)dst, bytes));
+  HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return MM_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace

@@ -1,4 +1,4 @@
-// Internal declarations shared by mm_tables.cpp (host tables) and mm_kernels.hip (device + ABI).
+// Internal declarations shared by mm_tables.cpp (host tables) and the .hip translation units (device code + C ABI).
 #ifndef MM_INTERNAL_H
 #define MM_INTERNAL_H
 
