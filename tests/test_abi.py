@@ -209,7 +209,8 @@ def test_sample_count_bound():
     """The radix-16 kernels index samples with 32-bit offsets (4 * index in the wave-per-frame kernel): the C ABI
     refuses clips beyond 2^29 - 8192 samples (9 hours at 16 kHz) instead of wrapping.  No GPU: a NULL plan is
     rejected first, so the bound is read from the header comment and the source."""
-    src = open(os.path.join(ROOT, "modulation_mfcc_amd", "csrc", "mm_api.hip")).read()
+    csrc = os.path.join(ROOT, "modulation_mfcc_amd", "csrc")
+    src = open(os.path.join(csrc, "mm_api.hip")).read() + open(os.path.join(csrc, "mm_plan.h")).read()
     assert "#define MM_MAX_SAMPLES (((int64_t)1 << 29) - 8192)" in src
     assert "if (n_samples > MM_MAX_SAMPLES) return MM_ERR_INVALID_ARG;" in src
 
