@@ -599,6 +599,13 @@ def main():
         (with the driver's 5 warmup steps = 2.5 ms alone, the 10 ms timed region falls into the clock ramp and reads
         15 % slow: 0.50 vs 0.43 ms per step on the same box)."""
         ex = {}
+        # ---- ONE recording through the drop-in call, as the reference's UI makes it: FIRST of the sections -- its host
+        # work (file I/O, Python, the oracle's CPU time) leaves the GPU idle, and the headline region must not follow it
+        if world == 1:
+            try:
+                ex["refdefault_call"] = time_reference_call(torch, dev)
+            except Exception as e:
+                ex["refdefault_call"] = {"error": repr(e)}
         # ---- the rows either side of the hot path (SURVEY 8(f) N1 - N4), for the record (N = 1 only); FIRST: measured
         # right before the headline region their double-precision kernels left it 10 % slower (0.49 vs 0.44 ms) ----
         if world == 1:
@@ -695,11 +702,6 @@ def main():
                 torch.cuda.empty_cache()
             if "c2" in ex and "refdefault" in ex:
                 ex["refdefault"]["vs_c2_per_frame_mel"] = ex["refdefault"]["ns_per_frame_mel"] / ex["c2"]["ns_per_frame_mel"]
-            try:
-                ex["refdefault_call"] = time_reference_call(torch, dev)
-            except Exception as e:
-                ex["refdefault_call"] = {"error": repr(e)}
-
         return ex
 
     extras = run_extras() if not a.no_extra else {}

@@ -591,8 +591,11 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       p->s16_nr = 0;
       if (p->w16_ok) {
         const int span = 63 * cfg->hop_length + 512;
-        const int nr = span <= 3 * 4096 ? 3 : (span <= 4 * 4096 ? 4 : 0);
-        const size_t lds = nr ? (size_t)(nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tab16.size() * 4 : 0;
+        // 16-byte staging groups per thread: the fewest that hold the tile's samples (1 / 2 for short hops -- without
+        // pre-emphasis only: those instantiations do not exist -- leave LDS for the log-mel tile of a 128-filter bank)
+        int nr = span <= 4096 ? 1 : span <= 2 * 4096 ? 2 : span <= 3 * 4096 ? 3 : (span <= 4 * 4096 ? 4 : 0);
+        if (nr && nr < 3 && cfg->preemph != 0.0f) nr = 3;
+        const size_t lds = nr ? (size_t)MM_S16_TAB_OFF(nr) + tab16.size() * 4 : 0;
         const bool ok = nr && lds <= MM_LM_LDS_MAX && set_s16_attr(MM_LM_LDS_MAX);
         if (ok) { p->s16_nr = nr; p->s16_lds_bytes = lds; }
       }
@@ -625,7 +628,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
                 const int k = 16 * kb + (l & 15), m = 4 * s + (l >> 4);
                 if (k < cfg->n_mfcc && m < cfg->n_mels) dcta[((size_t)kb * nk + s) * 64 + l] = dct[(size_t)k * cfg->n_mels + m];
               }
-          const size_t tab_end = (size_t)(p->s16_nr == 3 ? MM_S16_TAB_OFF(3) : MM_S16_TAB_OFF(4)) + tabf.size() * 4;
+          const size_t tab_end = (size_t)MM_S16_TAB_OFF(p->s16_nr) + tabf.size() * 4;
           p->s16f_lt_off = (unsigned)align_up(tab_end, 16);
           p->s16f_dcta_off = p->s16f_lt_off + 2u * (unsigned)lt_rows * 320u;
           p->s16f_red_off = (unsigned)align_up((size_t)p->s16f_dcta_off + dcta.size() * 4, 16);
