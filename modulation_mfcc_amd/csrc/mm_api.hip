@@ -397,7 +397,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
   p->d_k2_lane_tab = p->d_k2_mel_lane = nullptr; p->k2_ok = 0; p->d_window_e = nullptr; p->embed = 1;
   p->d_rf2k_lane_tab = nullptr; p->rf2k_ok = 0;
   p->d_h16_tab = nullptr; p->d_h16_part = nullptr; p->h16_ok = 0;
-  p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0;
+  p->d_s16f_tab = p->d_s16f_dcta = nullptr; p->d_s16f_part = nullptr; p->s16f_ok = 0; p->s16f_flags = 0;
   p->d_m12_a = p->d_m12_dct = p->d_zeros = nullptr; p->m12_ok = 0; p->variant = 0; p->no_fuse = 0; p->no_fuse_tail = 0; p->s16f_red_off = 0; p->d_dctfm_a = nullptr; p->d_dctw_a = nullptr; p->dctw_nk = p->dctw_ch = 0;
   p->sw_n_runs = p->sw_n_tab16 = 0; p->lm_lds_bytes = 0;
   p->num_cus = 256;
@@ -599,17 +599,36 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         const bool ok = nr && lds <= MM_LM_LDS_MAX && set_s16_attr(MM_LM_LDS_MAX);
         if (ok) { p->s16_nr = nr; p->s16_lds_bytes = lds; }
       }
-      // staged-sample variant with the DCT fused in: parts 3 / 7 / 11 / 15 of a weighted partition are half
-      // size and their waves compute one frame block's DCT each (10 MFMAs + 20 LDS reads ~ half a mel share)
-      if (p->s16_nr) {
-        const double wts[16] = {1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W};
-        double extra[16];
-        for (int w = 0; w < 16; ++w) extra[w] = wts[w] < 1.0 ? 700.0 : 0.0;     // cost model units: instructions
-        mm::MelSweep swf;
+      // staged-sample variant with the DCT fused in.  Two layouts of the log-mel tile Lt[filter][frame]:
+      //   double buffered (up to ~64 filters): parts 3 / 7 / 11 / 15 of a weighted partition are half size and their waves
+      //     compute one frame block's DCT each under phase B (10 MFMAs + 20 LDS reads ~ half a mel share at 40 mel);
+      //   single (a 128-filter bank: 40 KB once, 80 KB twice does not fit beside the power tile): equal mel parts, waves
+      //     0 .. 3 -- one per SIMD -- take the previous tile's DCT at the top of phase A.
+      // Filters without a single weight (fmax above Nyquist: 26 of the reference default's 128) are handled analytically
+      // (Logmel512Params::skip_empty): their runs are flagged, their A-operand columns zero, E[k] follows the A operands.
+      if (p->s16_nr && cfg->n_mels <= 256) {
         const int lt_rows = (cfg->n_mels + 3) & ~3, nk = lt_rows / 4, kbn = (cfg->n_mfcc + 15) / 16;
-        if (mm::build_mel_sweep(*ce, melp, 16, &swf, wts)) {
+        std::vector<char> empty(cfg->n_mels, 1);
+        int n_empty = 0;
+        for (int m = 0; m < cfg->n_mels; ++m) {
+          for (int k = 0; k < 257 && empty[m]; ++k) if (melp[(size_t)m * 257 + k] != 0.0f) empty[m] = 0;
+          n_empty += empty[m];
+        }
+        const bool skip = n_empty > 0 && n_empty < cfg->n_mels;
+        for (int layout = 0; layout < 2 && !p->s16f_ok; ++layout) {
+          const bool single = layout == 1;
+          const double wts_d[16] = {1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W};
+          double extra[16];
+          for (int w = 0; w < 16; ++w) extra[w] = (!single && wts_d[w] < 1.0) ? 700.0 : 0.0;     // cost model units: instructions
+          mm::MelSweep swf;
+          if (!mm::build_mel_sweep(*ce, melp, 16, &swf, single ? nullptr : wts_d)) break;
           mm::MelRuns rf;
           mm::build_mel_runs(*ce, swf, 16, &rf);
+          if (skip)
+            for (size_t r = 0; r < rf.hdr.size() / 4; ++r) {
+              const int d = rf.hdr[4 * r + 3];
+              if (d >= 0 && d < cfg->n_mels && empty[d]) rf.hdr[4 * r + 0] |= 1 << 16;
+            }
           std::vector<float> tabf(rf.hdr.size() + rf.grp.size());
           std::memcpy(tabf.data(), rf.hdr.data(), rf.hdr.size() * 4);
           std::memcpy(tabf.data() + rf.hdr.size(), rf.grp.data(), rf.grp.size() * 4);
@@ -618,29 +637,45 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
           const std::vector<int> partf = balance_parts_over_simds(rf, extra, &wave_of_part);
           unsigned long long roles = ~0ull;
           for (int f = 0; f < 4; ++f) {
-            const int w = wave_of_part[4 * f + 3];
+            const int w = single ? f : wave_of_part[4 * f + 3];       // single: waves 0 .. 3 sit on the four SIMDs
             roles = (roles & ~(0xFull << (4 * w))) | ((unsigned long long)f << (4 * w));
           }
-          std::vector<float> dcta((size_t)kbn * nk * 64, 0.0f);
+          // A operands dct[16 kb + (l & 15)][4 s + (l >> 4)] (zero columns for skipped filters), then E[k] = the skipped
+          // filters' column sum (float64 sum, rounded once)
+          std::vector<float> dcta((size_t)kbn * nk * 64 + (size_t)kbn * 16 + 8, 0.0f);      // A | E | 256 "is empty" bits
           for (int kb = 0; kb < kbn; ++kb)
             for (int s = 0; s < nk; ++s)
               for (int l = 0; l < 64; ++l) {
                 const int k = 16 * kb + (l & 15), m = 4 * s + (l >> 4);
-                if (k < cfg->n_mfcc && m < cfg->n_mels) dcta[((size_t)kb * nk + s) * 64 + l] = dct[(size_t)k * cfg->n_mels + m];
+                if (k < cfg->n_mfcc && m < cfg->n_mels && !(skip && empty[m]))
+                  dcta[((size_t)kb * nk + s) * 64 + l] = dct[(size_t)k * cfg->n_mels + m];
               }
+          if (skip)
+            for (int k = 0; k < cfg->n_mfcc; ++k) {
+              double e = 0.0;
+              for (int m = 0; m < cfg->n_mels; ++m) if (empty[m]) e += (double)dct[(size_t)k * cfg->n_mels + m];
+              dcta[(size_t)kbn * nk * 64 + k] = (float)e;
+            }
+          if (skip) {
+            unsigned bits[8] = {0};
+            for (int m = 0; m < cfg->n_mels; ++m) if (empty[m]) bits[m >> 5] |= 1u << (m & 31);
+            std::memcpy(&dcta[(size_t)kbn * nk * 64 + (size_t)kbn * 16], bits, sizeof(bits));
+          }
           const size_t tab_end = (size_t)MM_S16_TAB_OFF(p->s16_nr) + tabf.size() * 4;
           p->s16f_lt_off = (unsigned)align_up(tab_end, 16);
-          p->s16f_dcta_off = p->s16f_lt_off + 2u * (unsigned)lt_rows * 320u;
+          p->s16f_dcta_off = p->s16f_lt_off + (single ? 1u : 2u) * (unsigned)lt_rows * 320u;
           p->s16f_red_off = (unsigned)align_up((size_t)p->s16f_dcta_off + dcta.size() * 4, 16);
           p->s16f_lds_bytes = (size_t)p->s16f_red_off + 2 * 16 * 8;
-          if (p->s16f_lds_bytes <= MM_LM_LDS_MAX &&
-              upload(&p->d_s16f_tab, tabf.data(), tabf.size() * 4) == MM_OK &&
+          if (p->s16f_lds_bytes > MM_LM_LDS_MAX) continue;          // try the single-tile layout
+          if (upload(&p->d_s16f_tab, tabf.data(), tabf.size() * 4) == MM_OK &&
               upload(&p->d_s16f_part, partf.data(), partf.size() * 4) == MM_OK &&
               upload(&p->d_s16f_dcta, dcta.data(), dcta.size() * 4) == MM_OK) {
             p->s16f_n_runs = (int)(rf.hdr.size() / 4); p->s16f_n_tab16 = (int)(tabf.size() / 4);
             p->s16f_lt_rows = lt_rows; p->s16f_nk = nk; p->s16f_kb = kbn; p->s16f_roles = roles;
+            p->s16f_flags = (single ? MM_S16F_SINGLE : 0) | (skip ? MM_S16F_SKIP : 0);
             p->s16f_ok = 1;
           }
+          break;
         }
       }
       // 12-wave MFMA-mel variant (mm_logmel12m.hip.inc): banded A-operand table, unit lists, LDS budget
@@ -911,6 +946,7 @@ struct StftOut {
   float* mod = nullptr;        // in: modulation-spectrum output wanted from the same launch (clip mode)
   int n_mod = 0;
   bool fused_tail = false;     // out: clamp fix-up and trajectory rFFT were part of the launch (no keys used)
+  bool skip_empty = false;     // out: filters without weights were handled analytically (rows not stored, E[k] L0 in the DCT)
 };
 
 // Clip mode of the staged-sample kernel (whole clips per workgroup, tail fused in): the trajectory length must be
@@ -1047,6 +1083,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.out_mfcc = nullptr; q.key_nmin = nullptr; q.dct_a = nullptr; q.n_mfcc = 0; q.dct_nk = q.dct_kb = q.lt_rows = 0;
     q.lt_off = q.dcta_off = 0; q.dct_roles = ~0ull;
     q.out_mod = nullptr; q.dct_t = nullptr; q.n_mod = q.dct_kp = 0; q.top_db = -1.0f; q.red_off = 0;
+    q.dct_flags = 0; q.lt_b2 = 0;
     q.lane_tab = p->d_lane_tab;
     q.preemph = p->cfg.preemph;
     if (q.n_tiles > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
@@ -1062,11 +1099,13 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
         if (mode == 1 && o.mfcc != nullptr && p->s16f_ok && o.key_nmin != nullptr && !p->no_fuse) {
           // DCT fused in: its own run table (half-size parts for the four DCT waves)
           o.fused_dct = true;
+          o.skip_empty = (p->s16f_flags & MM_S16F_SKIP) != 0;
           q.mel_tab = (const float4*)p->d_s16f_tab; q.n_runs = p->s16f_n_runs; q.n_tab16 = p->s16f_n_tab16;
           q.wave_part = p->d_s16f_part;
           q.out_mfcc = o.mfcc; q.key_nmin = o.key_nmin; q.dct_a = p->d_s16f_dcta; q.n_mfcc = p->cfg.n_mfcc;
           q.dct_nk = p->s16f_nk; q.dct_kb = p->s16f_kb; q.lt_rows = p->s16f_lt_rows;
           q.lt_off = p->s16f_lt_off; q.dcta_off = p->s16f_dcta_off; q.dct_roles = p->s16f_roles;
+          q.dct_flags = p->s16f_flags; q.lt_b2 = (p->s16f_flags & MM_S16F_SINGLE) ? 0 : p->s16f_lt_rows;
           if (p->cfg.top_db < 0.0f) q.out_logmel = nullptr;      // the rows only feed the clamp fix-up
           lds = p->s16f_lds_bytes;
           q.red_off = p->s16f_red_off;
@@ -1185,8 +1224,11 @@ int mm_mfcc_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_sampl
       // the kernel stored DCT(unclamped rows): only clips with min < max - top_db need the clamped DCT
       const int64_t bpc = (T + 255) / 256;
       if (batch * bpc > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+      // (o.skip_empty: the kernel that ran treated the filters without weights analytically -- the staged-sample kernel)
       hipLaunchKernelGGL(dct_fixup_kernel, dim3((unsigned)(batch * bpc)), dim3(256), 0, st, logmel, keys, keys + batch,
-                         p->d_dct_t, d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db);
+                         p->d_dct_t, d_mfcc, T, p->cfg.n_mels, p->cfg.n_mfcc, p->kp, p->cfg.top_db,
+                         o.skip_empty ? p->d_s16f_dcta + (size_t)p->s16f_kb * p->s16f_nk * 64 : nullptr,
+                         p->cfg.amin, p->db_offset);
     } else if (o.is_fm && p->d_dctw_a && !p->no_fuse) {
       // frame-major rows of the wave-per-frame kernel: clamp + DCT on the matrix pipe, a wave per 16-frame tile
       const int64_t n_items = batch * ((T + 15) / 16);
