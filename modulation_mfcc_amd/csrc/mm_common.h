@@ -135,6 +135,13 @@ typedef float mm_v4f __attribute__((ext_vector_type(4)));
 typedef unsigned mm_v2u __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) MmFloat4U { float x, y, z, w; };
 
+// The value a filter without weights takes in the fused kernels' phase B: 10 log10(max(amin, 0)) - db_offset exactly as
+// the kernels evaluate it (one fused multiply-add of the hardware log2).  An explicit fma: written as a product and a
+// difference the compiler contracts it into whatever consumes it (thr - L0 became fma(-c, log, thr): one ulp off).
+__device__ __forceinline__ float mm_empty_level(float amin, float db_offset) {
+  return __builtin_fmaf(3.0102999566398120f, __builtin_amdgcn_logf(amin), -db_offset);
+}
+
 #define MM_LM_LDS_MAX 163840     // the CU's whole LDS: what a single workgroup may declare (160 KiB)
 #define MM_DCT_KB 16            // DCT coefficients per accumulator block of the lane <-> frame clamp + DCT kernels
 

@@ -759,6 +759,70 @@ def test_headline_config_through_the_headline_entry_point(gpu):
     assert torch.allclose(e_time, e_freq, rtol=1e-4)
 
 
+_EMPTY_CFGS = [
+    # (cfg, n_samples, what)
+    (dict(sr=10000, n_fft=512, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), 50000,
+     "the reference's own default call: 26 of 128 filters above Nyquist; one log-mel tile in LDS (DCT at the end of phase A)"),
+    (dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=10000.0), 160000,
+     "BASELINE shape with the reference's maxFreq: filter 39 empty; two log-mel tiles"),
+    (dict(sr=44100, n_fft=512, win_length=441, hop_length=110, n_mels=96, n_mfcc=20, fmin=60.0, fmax=10000.0), 88200,
+     "44.1 kHz: empty filters scattered through the low bands (narrower than a bin); n_mfcc 20: two coefficient blocks"),
+    (dict(sr=10000, n_fft=512, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0, top_db=-1.0), 50000,
+     "no clamp: the empty filters' share is E[k] L0 alone"),
+]
+
+
+@pytest.mark.parametrize("kw,n,what", _EMPTY_CFGS, ids=[f"empty{i}" for i in range(len(_EMPTY_CFGS))])
+def test_empty_filters_are_handled_analytically(kw, n, what, gpu):
+    """Filters without a single weight always read 10 log10(amin) = L0 (librosa warns 'Empty filters detected'; the
+    reference's default maxFreq = 10000 at 10 kHz gives 26 of 128).  The fused kernel neither computes nor stores them,
+    keeps them out of the clip minimum (else EVERY clip of such a plan would take the clamp fix-up) and adds their share
+    of the DCT analytically: E[k] L0 in the accumulators + E[k] max(0, thr - L0) once the clip's threshold is known.
+    Against the oracle and against the separate clamp + DCT kernel over all rows, for every kind of clip: loud (thr above
+    L0: the add), 60 dB down (thr below L0: nothing), quiet tail (live filters clamp: the full fix-up, bit-equal to the
+    separate kernel), digital silence (max = L0), an impulse; tile mode (mm_mfcc_f32) and clip mode
+    (mm_mfcc_modspec_f32, one launch) bit-equal."""
+    import torch
+    plan = _plan(kw)
+    assert plan.kernel_path == "radix16-w16s" and plan.fused_dct
+    B = 256
+    g = torch.Generator(device=gpu).manual_seed(11)
+    sr = kw["sr"]
+    t = torch.arange(n, device=gpu, dtype=torch.float64) / sr
+    base = (0.3 * torch.sin(2 * np.pi * 220 * t) * (1 + 0.5 * torch.sin(2 * np.pi * 4 * t))).float()
+    audio = 0.05 * torch.randn((B, n), generator=g, device=gpu) + base[None, :]
+    audio[1::8] *= 1e-3                        # 60 dB down: thr < L0, no correction
+    audio[2::8, n // 2:] *= 1e-6               # quiet tail: live filters clamp
+    audio[3::8] = 0.0                          # digital silence
+    audio[4::8] = 0.0
+    audio[4::8, n // 3] = 1.0                  # an impulse in silence
+    okw = dict(kw)
+    okw["top_db"] = None if kw.get("top_db", 80.0) < 0 else kw.get("top_db", 80.0)
+    ocfg = O.OracleConfig(**okw)
+    m = plan.mfcc(audio)
+    assert bool(torch.isfinite(m).all())
+    for i in (0, 1, 2, 3, 4, B - 1):
+        mfcc_close(m[i].cpu().numpy(), O.mfcc(audio[i].cpu().numpy(), ocfg), f"{what}: clip {i}")
+    prev = plan.set_fuse_dct(False)
+    try:
+        assert not plan.fused_dct
+        m0 = plan.mfcc(audio)
+    finally:
+        plan.set_fuse_dct(prev)
+    scale = m0.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
+    assert float(((m - m0).abs() / scale).max()) <= 2e-6           # float32 round-off of a differently ordered sum
+    if okw["top_db"] is not None:
+        assert torch.equal(m[2::8], m0[2::8])                      # clips that take the full fix-up: the separate kernel's bits
+    T = m.shape[2]
+    if plan.fused_tail(B, n):
+        m2, s2 = plan.mfcc_modspec(audio)
+        assert torch.equal(m2, m), float((m2 - m).abs().max())
+        wm = O.modspec(O.mfcc(audio[0].cpu().numpy(), ocfg))
+        assert np.abs(s2[0].cpu().numpy() - wm).max() <= 1e-4 * np.abs(wm).max()
+    else:
+        assert plan.cfg.mod_fft_len(T) > 1024
+
+
 def test_configs4_workload_on_one_gpu(gpu):
     """BASELINE configs[4]'s WORKLOAD -- 8192 clips x 10 s x 16 kHz, MFCC + modulation spectrum -- on one GPU (5.2 GB of
     audio; the 8-GPU run gives each rank one eighth of exactly this batch).  (a) the whole batch through
