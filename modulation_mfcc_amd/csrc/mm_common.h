@@ -135,6 +135,28 @@ typedef float mm_v4f __attribute__((ext_vector_type(4)));
 typedef unsigned mm_v2u __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) MmFloat4U { float x, y, z, w; };
 
+// fmaxf / fminf as ONE instruction.  The compiler quiets possible signalling NaNs first (a v_max_f32 x, x "canonicalise" in
+// front of every operand whose origin it cannot see: three extra instructions per max / min pair in the mel walk); the
+// hardware instruction already implements IEEE maxNum / minNum (a NaN operand loses, sNaN is quieted), i.e. fmaxf's result.
+__device__ __forceinline__ float mm_max_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// in-place forms (the accumulator is a tied operand: no copies where the update sits in one arm of a branch)
+__device__ __forceinline__ void mm_max_acc(float& acc, float b) { asm("v_max_f32 %0, %0, %1" : "+v"(acc) : "v"(b)); }
+__device__ __forceinline__ void mm_min_acc(float& acc, float b) { asm("v_min_f32 %0, %0, %1" : "+v"(acc) : "v"(b)); }
+__device__ __forceinline__ float mm_max_raw_s(float a, float s_uniform) {      // second operand wave-uniform (an SGPR)
+  float r;
+  asm("v_max_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(s_uniform));
+  return r;
+}
+__device__ __forceinline__ float mm_min_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // The value a filter without weights takes in the fused kernels' phase B: 10 log10(max(amin, 0)) - db_offset exactly as
 // the kernels evaluate it (one fused multiply-add of the hardware log2).  An explicit fma: written as a product and a
 // difference the compiler contracts it into whatever consumes it (thr - L0 became fma(-c, log, thr): one ulp off).
