@@ -767,7 +767,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       }
       p->wpf_group_max = group_max;
       std::vector<float> lt = wpf_lane_table(R, win.data(), tw.data());
-      const int macc_stride = (cfg->n_mels + 63) / 64 * 64;
+      const int macc_stride = (cfg->n_mels + 2 + 63) / 64 * 64;      // slots -1 .. n_mels: no bounds tests in the sweep
       const int F = 4 / R;
       const int xbuf = (R == 1) ? 1280 : 1152;
       const int pbuf = F * (NC + NC / 16 + 4);
@@ -1021,7 +1021,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.groups_per_clip = (q.n_frames + F - 1) / F;
     q.total_groups = batch * q.groups_per_clip;
     q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
-    q.macc_stride = (p->cfg.n_mels + 63) / 64 * 64; q.waves_per_wg = p->wpf_waves;
+    q.macc_stride = (p->cfg.n_mels + 2 + 63) / 64 * 64; q.waves_per_wg = p->wpf_waves;
     q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane; q.group_max = p->wpf_group_max;
     q.out_logmel = o.logmel; q.clip_key = o.key_max; q.out_power = o.power;
     if (o.frame_major) { q.sB = q.n_frames * q.n_mels; q.sT = q.n_mels; q.sM = 1; }

@@ -135,6 +135,17 @@ typedef float mm_v4f __attribute__((ext_vector_type(4)));
 typedef unsigned mm_v2u __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) MmFloat4U { float x, y, z, w; };
 
+// Global memory through buffer descriptors (wave-uniform base in SGPRs, 32-bit per-lane byte offset, immediate
+// offsets folded into the instruction, reads past num_records return 0): the 64-bit address pairs of ~60 plain
+// loads do not fit beside the transform in the 128 VGPRs of a 16-wave workgroup.
+__device__ __forceinline__ float mm_buf_f32(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float2 mm_buf_f32x2(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  const mm_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+  return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+
 // fmaxf / fminf as ONE instruction.  The compiler quiets possible signalling NaNs first (a v_max_f32 x, x "canonicalise" in
 // front of every operand whose origin it cannot see: three extra instructions per max / min pair in the mel walk); the
 // hardware instruction already implements IEEE maxNum / minNum (a NaN operand loses, sNaN is quieted), i.e. fmaxf's result.
