@@ -297,9 +297,11 @@ def time_next_rows(torch, dev):
     out["N3_rms_256x160000"] = hbm(ms, 256 * 160000 * 4 + 256 * 1001 * 4, "samples in + envelope out")
     ms = t(lambda: calc.hilbert_envelope_batch(x))
     out["N3_hilbert_256x160000"] = hbm(ms, 256 * 160000 * 8, "samples in + envelope out (the implementation: two clips per "
-                                       "complex transform, four fused FFT passes over 128 complex rows, the clips read "
-                                       "three times: 1.8 GB)")
-    out["N3_hilbert_256x160000"]["implementation_bytes"] = 128 * 160000 * 8 * 2 * 4 + 256 * 160000 * 4 * 3
+                                       "complex transform; forward radix-256 pass | forward radix-625 pass + mask + inverse "
+                                       "radix-625 pass in ONE launch | inverse radix-256 pass + envelope: three round trips "
+                                       "of 128 complex rows minus the ends, the clips read three times (maxima, pairing, envelope), the envelope "
+                                       "written: 8 x 164 MB = 1.31 GB)")
+    out["N3_hilbert_256x160000"]["implementation_bytes"] = 128 * 160000 * 8 * 4 + 256 * 160000 * 4 * 4
     from modulation_mfcc_amd import applyFilter
     env = calc.hilbert_envelope_batch(x)                 # float32, as the reference filters it (odd extension in float32)
     ms = t(lambda: applyFilter(env, 16000.0, filt="iir", cutOff=[12.0], filtLen=6))
