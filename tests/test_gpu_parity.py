@@ -1360,6 +1360,19 @@ def test_hilbert_envelope_on_device(dt, gpu):
         got = calc.hilbert_envelope_batch(_dev(x, gpu)).cpu().numpy()
         for r in range(7):
             assert np.abs(got[r] - want[r]).max() <= tol * want[r].max() + 1e-300, (n, r, np.abs(got[r] - want[r]).max(), want[r].max())
+    # scipy.signal.hilbert is strictly per row -- a clip with a NaN or an infinity comes out NaN, its pair
+    # partner (the clip next to it shares its complex transform) must not: such a clip is kept out of its pair
+    for n in (1000, 160000):
+        x = rng.standard_normal((6, n)).astype(dt)
+        x[1, n // 2] = np.nan                     # partner: row 0
+        x[2, 7] = np.inf                          # partner: row 3
+        x[5, 0] = -np.inf                         # partner: row 4
+        got = calc.hilbert_envelope_batch(_dev(x, gpu)).cpu().numpy()
+        for r in (1, 2, 5):
+            assert np.isnan(got[r]).all(), (n, r)
+        for r in (0, 3, 4):
+            want = np.abs(scipy.signal.hilbert(x[r].astype(np.float64)))
+            assert np.isfinite(got[r]).all() and np.abs(got[r] - want).max() <= tol * want.max(), (n, r)
     assert len(calc._HILBERT_PLANS) <= calc.HILBERT_MAX_PLANS          # table memory stays bounded over many lengths
     # a strided view (every other row of a bigger batch) and a single clip
     big = _dev(rng.standard_normal((6, 3001)).astype(dt), gpu)
