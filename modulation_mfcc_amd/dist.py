@@ -5,14 +5,13 @@ Clips are independent (every reduction of the hot path -- the per-clip top_db ma
 rFFT -- stays inside a clip), so there is no mid-pipeline exchange: rank r computes
 its contiguous block of clips and the only collective is the final gather.
 
-What travels: the modulation spectrum is a fixed linear map (zero-padded rFFT) of the MFCC
-trajectories, i.e. pure redundancy on the wire -- as many bytes again as the MFCCs themselves, over
-point-to-point xGMI links whose ~50 GB/s per direction make the gather, not the kernels, the slow
-part of a step at N >= 2.  By default (``modspec_on_root=True``) only the MFCC slab is gathered and
-the root runs the trajectory rFFT over the gathered [B_total, n_mfcc, T] block (one launch, ~0.3 ms
-for 8192 clips); ``modspec_on_root=False`` is the literal variant: every rank computes its own
-modulation spectrum and MFCC + modulation spectrum share one flat float32 slab per rank so that a
-single collective moves both.
+Two variants of what travels.  The default (``modspec_on_root=False``) is the literal one: every rank computes the
+MFCCs AND the modulation spectrum of its clips (one fused launch where the plan can) and both arrays share one flat
+float32 slab per rank, so that a single collective moves both.  ``modspec_on_root=True`` exploits that the modulation
+spectrum is a fixed linear map (zero-padded rFFT) of the MFCC trajectories, i.e. redundancy on the wire -- as many bytes
+again as the MFCCs themselves over point-to-point xGMI links: only the MFCC slab is gathered and the root runs the
+trajectory rFFT over the gathered [B_total, n_mfcc, T] block (one launch, ~0.3 ms for 8192 clips) -- half the bytes, at
+the price of extra work on the root.  bench.py times both with equal steps and reports them side by side.
 """
 from __future__ import annotations
 
@@ -165,15 +164,15 @@ class PipelinedGather:
 
 
 def mfcc_modspec_sharded(audio_all_or_local, cfg: MfccConfig, *, with_modspec=True, dst=0, group=None,
-                         is_local=False, compute=None, modspec_on_root=True, root_modspec=None):
+                         is_local=False, compute=None, modspec_on_root=False, root_modspec=None):
     """Run the hot path on this rank's clips and gather everything on ``dst``.
 
     audio_all_or_local  [B_total, n] (every rank holds or can index the full batch) or, with
                         is_local=True, this rank's own [B_local, n] block
     compute             callable(audio_local, layout, slab) filling ``slab``; defaults to the HIP
                         plan (tests inject a CPU stand-in to exercise the collective under gloo)
-    modspec_on_root     gather the MFCCs only and compute the modulation spectrum of the gathered block
-                        on ``dst`` (see the module docstring); False: every rank sends both
+    modspec_on_root     False (default): every rank sends MFCC + modulation spectrum; True: gather the MFCCs only and
+                        compute the modulation spectrum of the gathered block on ``dst`` (see the module docstring)
     root_modspec        callable(mfcc_all) -> modspec for the root-side variant (default: the HIP plan)
     Returns on dst: (mfcc [B_total, n_mfcc, T], modspec or None); elsewhere (None, None).
     """
