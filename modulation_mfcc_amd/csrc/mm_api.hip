@@ -475,6 +475,19 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         mm_plan_destroy(p);
         return rc;
       }
+      // batched form (stft_anyb_kernel): TWO frames per wave at once, for the small packed direct lengths whose tables
+      // sit in LDS on a wave per frame.  Measured per 1 025 024 frames (tools/any_time.py, forms 1 / 2 / 3 / 4 frames):
+      // n_fft 400: 1.49 / 1.24 / 1.25 / 1.56 ms; 600: 1.74 / 1.88 / 2.14 / 2.14; 800: 2.93 / 3.39 / 3.39 / 3.39 -- the
+      // batch fills the lanes of a 200-point frame's passes (25 / 40 butterflies), beyond that the LDS it takes costs
+      // occupancy and the next frame's register prefetch of the one-frame kernel is worth more.
+      ap.fb = 0;
+      if (ap.lds_tab && ap.tpf == 64 && ap.packed && ap.M == 0 && ap.nn <= 256) {
+        const int fb = 2;
+        const size_t per_wave = (size_t)2 * fb * ap.nn * 8;
+        if ((size_t)fb * (ap.nn + 2) * 4 <= (size_t)fb * ap.nn * 8 && 4 * per_wave + pack.size() * 4 <= 80 * 1024) {
+          ap.fb = fb; ap.fb_grp_bytes = (unsigned)per_wave;
+        }
+      }
     }
     const void* kfn[8] = {(const void*)stft_any_kernel<0, 64, false>, (const void*)stft_any_kernel<1, 64, false>,
                           (const void*)stft_any_kernel<0, 256, false>, (const void*)stft_any_kernel<1, 256, false>,
@@ -486,6 +499,9 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         mm_plan_destroy(p);
         return MM_ERR_HIP;
       }
+    if (hipFuncSetAttribute((const void*)stft_anyb_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)stft_anyb_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess)
+      p->any.fb = 0;
     p->any.ok = true;       // (the n_fft-specific set-up below does not apply; the trajectory rFFT set-up at the end does)
   }
   // n_fft 64 / 128 / 256 ride on the n_fft = 512 tile kernels: a frame zero-padded to 512 points around
@@ -914,6 +930,8 @@ int mm_plan_set_fuse_tail(mm_plan* p, int on) {
 
 int mm_plan_set_variant(mm_plan* p, int variant) {
   if (!p || variant < 0 || variant > MM_K_H16 || variant == MM_K_ANY) return MM_ERR_INVALID_ARG;   // (MM_K_ANY is not a choice: such plans have one kernel)
+  // (on an any-length plan the value selects that kernel's form instead -- 0 automatic, 1 one frame per wave, 2 .. 4
+  // frames per wave at once: development A/B, launch_stft)
   const int prev = p->variant;
   p->variant = variant;
   return prev;
@@ -981,6 +999,20 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.frames_per_group = ap.lds_tab ? 16 : 4; q.grp_bytes = ap.grp_bytes; q.b_off = ap.b_off; q.p_off = ap.p_off;
     q.tabpack = ap.d_tabpack; q.tab_floats = ap.tab_floats; q.o_tw = ap.o_tw; q.o_split = ap.o_split; q.o_chirp = ap.o_chirp;
     q.o_melw = ap.o_melw; q.o_mstart = ap.o_mstart; q.o_mlen = ap.o_mlen; q.o_moff = ap.o_moff;
+    // p->variant on an any-length plan: 1 = the one-frame-per-wave kernel (A/B), 2 .. 4 = frames per batch
+    const int fb = p->variant == 1 ? 0 : (p->variant >= 2 && p->variant <= 4 && ap.fb ? p->variant : ap.fb);
+    if (fb > 0) {
+      q.frames_per_group = 16 / fb * fb;                  // frames a wave walks (in batches of fb)
+      q.grp_bytes = (unsigned)((size_t)2 * fb * ap.nn * 8);
+      const int fpbb = 4 * q.frames_per_group;
+      const int64_t gridb = batch * ((q.n_frames + fpbb - 1) / fpbb);
+      if (gridb > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+      const size_t ldsb = (size_t)4 * q.grp_bytes + (size_t)ap.tab_floats * 4;
+      if (mode == 0) hipLaunchKernelGGL(stft_anyb_kernel<0>, dim3((unsigned)gridb), dim3(256), ldsb, st, q, fb);
+      else hipLaunchKernelGGL(stft_anyb_kernel<1>, dim3((unsigned)gridb), dim3(256), ldsb, st, q, fb);
+      HIP_TRY(hipGetLastError());
+      return MM_OK;
+    }
     const int G = 256 / ap.tpf, fpb = G * q.frames_per_group;
     const int64_t grid = batch * ((q.n_frames + fpb - 1) / fpb);
     if (grid > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;

@@ -13,6 +13,8 @@ struct AnyPlan {
   int tab_floats = 0, o_tw = 0, o_split = 0, o_chirp = 0, o_melw = 0, o_mstart = 0, o_mlen = 0, o_moff = 0;
   bool lds_tab = false;
   bool ok = false;
+  int fb = 0;                    // > 0: the batched kernel (stft_anyb_kernel) with this many frames per wave at once
+  unsigned fb_grp_bytes = 0;     // its LDS bytes per wave: two buffers of fb x nn complex points
 };
 
 // 12-wave matrix-pipe variant (mm_logmel12m.hip.inc): unit lists kept in the plan
