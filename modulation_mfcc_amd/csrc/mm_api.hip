@@ -792,6 +792,11 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       p->wpf_waves = 12;
       while (p->wpf_waves > 4 && (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes > MM_LM_LDS_MAX) p->wpf_waves -= 4;
       p->wpf_lds_bytes = (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes;
+      // sixteen waves (W16 instantiation: mel weights in LDS, power row over the exchange buffer), n_fft 1024 / 2048 log-mel mode
+      p->wpf_lds16 = (size_t)L * (MM_WPF_LT_PITCH + MM_WPF_ML_PITCH) * 4 + 16 * (size_t)(xbuf + F * 3 * macc_stride) * 4;
+      p->wpf_w16 = R >= 2 && p->wpf_lds16 <= MM_LM_LDS_MAX &&
+                   hipFuncSetAttribute((const void*)logmel_wpf_kernel<2, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)logmel_wpf_kernel<4, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
       const void* kfn[12] = {(const void*)logmel_wpf_kernel<1, 0, false>, (const void*)logmel_wpf_kernel<1, 1, false>,
                              (const void*)logmel_wpf_kernel<2, 0, false>, (const void*)logmel_wpf_kernel<2, 1, false>,
                              (const void*)logmel_wpf_kernel<4, 0, false>, (const void*)logmel_wpf_kernel<4, 1, false>,
@@ -1053,20 +1058,32 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.groups_per_clip = (q.n_frames + F - 1) / F;
     q.total_groups = batch * q.groups_per_clip;
     q.hop = p->cfg.hop_length; q.n_mels = p->cfg.n_mels; q.amin = p->cfg.amin; q.db_offset = p->db_offset;
-    q.macc_stride = (p->cfg.n_mels + 2 + 63) / 64 * 64; q.waves_per_wg = p->wpf_waves;
+    // The sixteen-wave form (W16) is built and correct (the GPU suite passes on it) but measured 1.5 % SLOWER than the
+    // twelve-wave form on configs[3] (1.90 - 1.92 vs 1.875 - 1.90 ms: its LDS reads of the mel weights and three spilled
+    // registers cost what the fourth wave per SIMD hides; docs/experiments.md R4) -- off unless a side build asks for it.
+#ifdef MM_WPF_W16_DEFAULT
+    const bool w16 = p->wpf_w16 && mode == 1 && p->cfg.preemph == 0.0f && p->variant != MM_K_WPF;
+#else
+    const bool w16 = false;
+#endif
+    q.macc_stride = (p->cfg.n_mels + 2 + 63) / 64 * 64; q.waves_per_wg = w16 ? 16 : p->wpf_waves;
     q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane; q.group_max = p->wpf_group_max;
     q.out_logmel = o.logmel; q.clip_key = o.key_max; q.out_power = o.power;
     if (o.frame_major) { q.sB = q.n_frames * q.n_mels; q.sT = q.n_mels; q.sM = 1; }
     else { q.sB = q.n_frames * q.n_mels; q.sT = 1; q.sM = q.n_frames; }
     o.is_fm = o.frame_major;
-    int64_t grid = (q.total_groups + p->wpf_waves - 1) / p->wpf_waves;
+    int64_t grid = (q.total_groups + q.waves_per_wg - 1) / q.waves_per_wg;
     if (grid > p->num_cus) grid = p->num_cus;
-    const dim3 blk(64 * p->wpf_waves);
-    const size_t lds = p->wpf_lds_bytes;
+    const dim3 blk(64 * q.waves_per_wg);
+    const size_t lds = w16 ? p->wpf_lds16 : p->wpf_lds_bytes;
     q.preemph = p->cfg.preemph;
     const bool pre = p->cfg.preemph != 0.0f;
 #define MM_WPF_LAUNCH(RR, MM) do { if (pre) hipLaunchKernelGGL((logmel_wpf_kernel<RR, MM, true>), dim3((unsigned)grid), blk, lds, st, q); \
                                    else hipLaunchKernelGGL((logmel_wpf_kernel<RR, MM, false>), dim3((unsigned)grid), blk, lds, st, q); } while (0)
+    if (w16) {
+      if (R == 2) hipLaunchKernelGGL((logmel_wpf_kernel<2, 1, false, true>), dim3((unsigned)grid), blk, lds, st, q);
+      else hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, true>), dim3((unsigned)grid), blk, lds, st, q);
+    } else
     if (R == 1) { if (mode == 0) MM_WPF_LAUNCH(1, 0); else MM_WPF_LAUNCH(1, 1); }
     else if (R == 2) { if (mode == 0) MM_WPF_LAUNCH(2, 0); else MM_WPF_LAUNCH(2, 1); }
     else { if (mode == 0) MM_WPF_LAUNCH(4, 0); else MM_WPF_LAUNCH(4, 1); }

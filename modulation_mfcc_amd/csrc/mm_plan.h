@@ -79,6 +79,8 @@ struct mm_plan {
   int rf2k_ok;
   int k2_ok, wpf_r, wpf_waves, wpf_group_max;
   size_t wpf_lds_bytes;
+  size_t wpf_lds16;                        // sixteen-wave form of the same kernel (W16): LDS bytes, and whether it applies
+  int wpf_w16;
   int num_cus;
   float* d_h16_tab; int* d_h16_part;       // 32-frame-tile / two-workgroup experiment (mm_logmel16h.hip.inc)
   int h16_ok, h16_n_pairs, h16_n_tab16;
