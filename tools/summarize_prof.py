@@ -27,7 +27,7 @@ def main(src, prefix):
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
     rows = list(csv.DictReader(open(stats)))
-    ours = ("logmel512", "logmel12m", "logmel_wpf", "stft_generic", "stft_any", "dct_clamp", "dct_fixup", "rfft16", "rfft_wpf", "rfft_generic", "mfcc_change", "decode_keys", "devcopy", "resample", "hb_pass", "chg_", "pcm_decode", "rms_tile", "sos_seg", "clip_tab", "stencil")
+    ours = ("logmel512", "logmel12m", "logmel_wpf", "stft_generic", "stft_any", "dct_clamp", "dct_fixup", "rfft16", "rfft_wpf", "rfft_generic", "mfcc_change", "decode_keys", "devcopy", "resample", "hb_pass", "hb_mid", "hb_row", "chg_", "pcm_decode", "rms_tile", "sos_seg", "clip_tab", "stencil")
     with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
