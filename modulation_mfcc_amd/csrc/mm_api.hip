@@ -502,6 +502,18 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     if (hipFuncSetAttribute((const void*)stft_anyb_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess ||
         hipFuncSetAttribute((const void*)stft_anyb_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess)
       p->any.fb = 0;
+    // two register stages (stft_reg2_kernel): n_fft 400 (8 x 25 complex points) and 800 (16 x 25)
+    p->any.reg2 = 0;
+    if (p->any.lds_tab && p->any.packed && p->any.M == 0 && (p->any.nn == 200 || p->any.nn == 400)) {
+      const int r1 = p->any.nn / 25;
+      const size_t need = 4 * (size_t)(r1 == 8 ? Reg2Geo<8>::WAVE_BYTES : Reg2Geo<16>::WAVE_BYTES) + (size_t)p->any.tab_floats * 4;
+      const void* rfn[4] = {(const void*)stft_reg2_kernel<8, 0>, (const void*)stft_reg2_kernel<8, 1>,
+                            (const void*)stft_reg2_kernel<16, 0>, (const void*)stft_reg2_kernel<16, 1>};
+      bool ok = need <= MM_LM_LDS_MAX;
+      for (int i = 0; i < 4 && ok; ++i)
+        ok = hipFuncSetAttribute(rfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
+      if (ok) p->any.reg2 = r1;
+    }
     p->any.ok = true;       // (the n_fft-specific set-up below does not apply; the trajectory rFFT set-up at the end does)
   }
   // n_fft 64 / 128 / 256 ride on the n_fft = 512 tile kernels: a frame zero-padded to 512 points around
@@ -1005,6 +1017,25 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.tabpack = ap.d_tabpack; q.tab_floats = ap.tab_floats; q.o_tw = ap.o_tw; q.o_split = ap.o_split; q.o_chirp = ap.o_chirp;
     q.o_melw = ap.o_melw; q.o_mstart = ap.o_mstart; q.o_mlen = ap.o_mlen; q.o_moff = ap.o_moff;
     // p->variant on an any-length plan: 1 = the one-frame-per-wave kernel (A/B), 2 .. 4 = frames per batch
+    // (5 = the batched LDS kernel where the two-stage register kernel is the default)
+    if (ap.reg2 && p->variant == 0) {
+      q.frames_per_group = 32;
+      const int fpbb = 4 * q.frames_per_group;
+      const int64_t gridb = batch * ((q.n_frames + fpbb - 1) / fpbb);
+      if (gridb > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
+      const size_t wb = ap.reg2 == 8 ? Reg2Geo<8>::WAVE_BYTES : Reg2Geo<16>::WAVE_BYTES;
+      const size_t ldsb = 4 * wb + (size_t)ap.tab_floats * 4;
+      const dim3 gd((unsigned)gridb), bd(256);
+      if (ap.reg2 == 8) {
+        if (mode == 0) hipLaunchKernelGGL((stft_reg2_kernel<8, 0>), gd, bd, ldsb, st, q);
+        else hipLaunchKernelGGL((stft_reg2_kernel<8, 1>), gd, bd, ldsb, st, q);
+      } else {
+        if (mode == 0) hipLaunchKernelGGL((stft_reg2_kernel<16, 0>), gd, bd, ldsb, st, q);
+        else hipLaunchKernelGGL((stft_reg2_kernel<16, 1>), gd, bd, ldsb, st, q);
+      }
+      HIP_TRY(hipGetLastError());
+      return MM_OK;
+    }
     const int fb = p->variant == 1 ? 0 : (p->variant >= 2 && p->variant <= 4 && ap.fb ? p->variant : ap.fb);
     if (fb > 0) {
       q.frames_per_group = 16 / fb * fb;                  // frames a wave walks (in batches of fb)

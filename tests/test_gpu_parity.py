@@ -604,6 +604,9 @@ _ANY_NFFT = [
     (dict(sr=16000, n_fft=400, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "400 = 2^4 5^2 (window == n_fft)"),
     (dict(sr=10000, n_fft=400, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "reference defaults, n_fft 400"),
     (dict(sr=10000, n_fft=1000, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "reference defaults, n_fft 1000"),
+    (dict(sr=32000, n_fft=800, win_length=800, hop_length=320, n_mels=64, n_mfcc=20, fmin=50.0, fmax=16000.0), "800 = 16 x 25 complex points: two register stages"),
+    (dict(sr=16000, n_fft=800, win_length=400, hop_length=37, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0, preemph=0.97), "800, odd hop, pre-emphasis"),
+    (dict(sr=16000, n_fft=400, win_length=400, hop_length=99, n_mels=26, n_mfcc=13, fmin=0.0, fmax=8000.0, preemph=0.95, top_db=30.0), "400, odd hop, pre-emphasis"),
     (dict(sr=16000, n_fft=600, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "600 = 2^3 3 5^2"),
     (dict(sr=22050, n_fft=1536, win_length=551, hop_length=220, n_mels=64, n_mfcc=20, fmin=0.0, fmax=11025.0), "1536 = 2^9 3"),
     (dict(sr=44100, n_fft=441, win_length=441, hop_length=147, n_mels=30, n_mfcc=12, fmin=50.0, fmax=20000.0), "441 = 3^2 7^2, odd"),
