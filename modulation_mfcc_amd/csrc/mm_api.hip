@@ -34,14 +34,6 @@ struct StftParams {
   int frames_per_wave;
 };
 
-__device__ __forceinline__ float load_sample(const float* __restrict__ a, int64_t i, int64_t n,
-                                             float pre) {
-  if (i < 0 || i >= n) return 0.0f;
-  float v = a[i];
-  if (pre != 0.0f && i > 0) v -= __fmul_rn(pre, a[i - 1]);   // rounded product, then subtract: no fma
-  return v;
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void stft_generic_kernel(StftParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -471,7 +463,16 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       // (direct lengths only: the Bluestein path's radix-2 stages are LDS-bound already -- with its twiddles in LDS too
       // n_fft 499 took 33 ms per 1 025 024 frames instead of 14.5)
       ap.lds_tab = ap.M == 0 && G * ap.grp_bytes + pack.size() * 4 <= budget;
-      if (ap.lds_tab && (rc = upload(&ap.d_tabpack, pack.data(), pack.size() * 4))) {
+      // two register stages (mm_reg2.hip): nn = R1 x R2 with an instantiation -- its own (smaller) buffers beside the tables
+      ap.reg2 = ap.reg2_r2 = 0;
+      {
+        int r1 = 0, r2 = 0;
+        if (ap.packed && ap.M == 0 && reg2_pick(ap.nn, &r1, &r2) && reg2_lds_bytes(r1, r2, ap.tab_floats) <= 80 * 1024 &&
+            reg2_set_attr(r1, r2, MM_LM_LDS_MAX)) {
+          ap.reg2 = r1; ap.reg2_r2 = r2;
+        }
+      }
+      if ((ap.lds_tab || ap.reg2) && (rc = upload(&ap.d_tabpack, pack.data(), pack.size() * 4))) {
         mm_plan_destroy(p);
         return rc;
       }
@@ -502,18 +503,6 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     if (hipFuncSetAttribute((const void*)stft_anyb_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess ||
         hipFuncSetAttribute((const void*)stft_anyb_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess)
       p->any.fb = 0;
-    // two register stages (stft_reg2_kernel): n_fft 400 (8 x 25 complex points) and 800 (16 x 25)
-    p->any.reg2 = 0;
-    if (p->any.lds_tab && p->any.packed && p->any.M == 0 && (p->any.nn == 200 || p->any.nn == 400)) {
-      const int r1 = p->any.nn / 25;
-      const size_t need = 4 * (size_t)(r1 == 8 ? Reg2Geo<8>::WAVE_BYTES : Reg2Geo<16>::WAVE_BYTES) + (size_t)p->any.tab_floats * 4;
-      const void* rfn[4] = {(const void*)stft_reg2_kernel<8, 0>, (const void*)stft_reg2_kernel<8, 1>,
-                            (const void*)stft_reg2_kernel<16, 0>, (const void*)stft_reg2_kernel<16, 1>};
-      bool ok = need <= MM_LM_LDS_MAX;
-      for (int i = 0; i < 4 && ok; ++i)
-        ok = hipFuncSetAttribute(rfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
-      if (ok) p->any.reg2 = r1;
-    }
     p->any.ok = true;       // (the n_fft-specific set-up below does not apply; the trajectory rFFT set-up at the end does)
   }
   // n_fft 64 / 128 / 256 ride on the n_fft = 512 tile kernels: a frame zero-padded to 512 points around
@@ -1017,22 +1006,13 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.tabpack = ap.d_tabpack; q.tab_floats = ap.tab_floats; q.o_tw = ap.o_tw; q.o_split = ap.o_split; q.o_chirp = ap.o_chirp;
     q.o_melw = ap.o_melw; q.o_mstart = ap.o_mstart; q.o_mlen = ap.o_mlen; q.o_moff = ap.o_moff;
     // p->variant on an any-length plan: 1 = the one-frame-per-wave kernel (A/B), 2 .. 4 = frames per batch
-    // (5 = the batched LDS kernel where the two-stage register kernel is the default)
+    // (where the two-stage register kernel is the default, 2 keeps the batched LDS kernel and 1 the one-frame kernel)
     if (ap.reg2 && p->variant == 0) {
-      q.frames_per_group = 32;
+      q.frames_per_group = reg2_frames_per_wave(ap.reg2);
       const int fpbb = 4 * q.frames_per_group;
       const int64_t gridb = batch * ((q.n_frames + fpbb - 1) / fpbb);
       if (gridb > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
-      const size_t wb = ap.reg2 == 8 ? Reg2Geo<8>::WAVE_BYTES : Reg2Geo<16>::WAVE_BYTES;
-      const size_t ldsb = 4 * wb + (size_t)ap.tab_floats * 4;
-      const dim3 gd((unsigned)gridb), bd(256);
-      if (ap.reg2 == 8) {
-        if (mode == 0) hipLaunchKernelGGL((stft_reg2_kernel<8, 0>), gd, bd, ldsb, st, q);
-        else hipLaunchKernelGGL((stft_reg2_kernel<8, 1>), gd, bd, ldsb, st, q);
-      } else {
-        if (mode == 0) hipLaunchKernelGGL((stft_reg2_kernel<16, 0>), gd, bd, ldsb, st, q);
-        else hipLaunchKernelGGL((stft_reg2_kernel<16, 1>), gd, bd, ldsb, st, q);
-      }
+      reg2_launch(ap.reg2, ap.reg2_r2, mode, dim3((unsigned)gridb), reg2_lds_bytes(ap.reg2, ap.reg2_r2, ap.tab_floats), st, q);
       HIP_TRY(hipGetLastError());
       return MM_OK;
     }

@@ -46,6 +46,15 @@ static int per_device_once(PerDeviceOnce& o, const char* what, F set) {
   return MM_OK;
 }
 
+// sample i of a clip, zero outside [0, n) (the centred frames are zero-padded), with optional pre-emphasis
+__device__ __forceinline__ float load_sample(const float* __restrict__ a, int64_t i, int64_t n,
+                                             float pre) {
+  if (i < 0 || i >= n) return 0.0f;
+  float v = a[i];
+  if (pre != 0.0f && i > 0) v -= __fmul_rn(pre, a[i - 1]);   // rounded product, then subtract: no fma
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------

@@ -1,4 +1,5 @@
-// Register butterflies of the library's own FFTs (radix 2 / 4 / 8 / 16, 3 / 9, 5 / 25, 7 / 49), templated on the scalar
+// Register butterflies of the library's own FFTs (radix 2 / 4 / 8 / 16, 3 / 9, 5 / 25, 7 / 49 and the composites
+// 10 / 12 / 15 / 20 / 24 / 32 / 40), templated on the scalar
 // type: used by the Hilbert envelope's Stockham passes (mm_hilbert.hip.inc) and by the any-length STFT (mm_anyfft.hip.inc).
 #pragma once
 #include "mm_common.h"
@@ -45,6 +46,13 @@ __device__ __forceinline__ const double (*hb_cs())[2] {
   else if constexpr (R == 7) return hb_cs7;
   else if constexpr (R == 9) return hb_cs9;
   else if constexpr (R == 25) return hb_cs25;
+  else if constexpr (R == 10) return hb_cs10;
+  else if constexpr (R == 12) return hb_cs12;
+  else if constexpr (R == 15) return hb_cs15;
+  else if constexpr (R == 20) return hb_cs20;
+  else if constexpr (R == 24) return hb_cs24;
+  else if constexpr (R == 32) return hb_cs32;
+  else if constexpr (R == 40) return hb_cs40;
   else return hb_cs49;
 }
 
@@ -117,6 +125,52 @@ __device__ __forceinline__ constexpr int hb_perm(int u) {
   return R == 16 ? 4 * (u & 3) + (u >> 2) : (R == 8 ? 2 * (u & 3) + (u >> 2) : u);
 }
 template <typename T, int R>
+__device__ __forceinline__ void hb_dft(hb_c<T> (&v)[R]);
+
+// forward DFT of A * B points, natural order out: n = B a + b, u = c + A d -- DFT-A over a for each b, * W_(AB)^(b c)
+// (quarter turns as exact swaps), DFT-B over b for each c
+template <typename T, int A, int B>
+__device__ __forceinline__ void hb_dft_rect(hb_c<T> (&v)[A * B]) {
+  constexpr int N = A * B;
+  const double (*cs)[2] = hb_cs<N>();
+  hb_c<T> w[B][A];                          // w[b][c]
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    hb_c<T> tmp[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) tmp[a] = v[B * a + b];
+    hb_dft<T, A>(tmp);
+#pragma unroll
+    for (int c = 0; c < A; ++c) {
+      const hb_c<T> x = tmp[hb_perm<A>(c)];
+      const int e = b * c;                  // < N
+      if (e == 0) {
+        w[b][c] = x;
+      } else if (4 * e == N) {
+        w[b][c] = hb_mul_mi(x);
+      } else if (2 * e == N) {
+        w[b][c].x = -x.x; w[b][c].y = -x.y;
+      } else if (4 * e == 3 * N) {
+        w[b][c].x = -x.y; w[b][c].y = x.x;
+      } else {
+        hb_c<T> tw;
+        tw.x = (T)cs[e][0]; tw.y = (T)(-cs[e][1]);
+        w[b][c] = hb_mul(x, tw);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < A; ++c) {
+    hb_c<T> tmp[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) tmp[b] = w[b][c];
+    hb_dft<T, B>(tmp);
+#pragma unroll
+    for (int d = 0; d < B; ++d) v[c + A * d] = tmp[hb_perm<B>(d)];
+  }
+}
+
+template <typename T, int R>
 __device__ __forceinline__ void hb_dft(hb_c<T> (&v)[R]) {
   if constexpr (R == 2) {
     hb_r2(v[0], v[1]);
@@ -140,6 +194,20 @@ __device__ __forceinline__ void hb_dft(hb_c<T> (&v)[R]) {
     hb_dft_square<T, 5>(v);
   } else if constexpr (R == 49) {
     hb_dft_square<T, 7>(v);
+  } else if constexpr (R == 10) {
+    hb_dft_rect<T, 2, 5>(v);
+  } else if constexpr (R == 12) {
+    hb_dft_rect<T, 4, 3>(v);
+  } else if constexpr (R == 15) {
+    hb_dft_rect<T, 3, 5>(v);
+  } else if constexpr (R == 20) {
+    hb_dft_rect<T, 4, 5>(v);
+  } else if constexpr (R == 24) {
+    hb_dft_rect<T, 8, 3>(v);
+  } else if constexpr (R == 32) {
+    hb_dft_rect<T, 16, 2>(v);
+  } else if constexpr (R == 40) {
+    hb_dft_rect<T, 8, 5>(v);
   } else {
     static_assert(R == 16, "radix");
     // n = 4 a + b, u = c + 4 d: DFT-4 over a, * W16^(b c), DFT-4 over b; V[c + 4 d] sits in v[4 c + d]

@@ -14,7 +14,7 @@ struct AnyPlan {
   bool lds_tab = false;
   bool ok = false;
   int fb = 0;                    // > 0: the batched kernel (stft_anyb_kernel) with this many frames per wave at once
-  int reg2 = 0;                  // 8 / 16: the two-stage register kernel (stft_reg2_kernel<R1>), nn = 25 R1
+  int reg2 = 0, reg2_r2 = 0;     // > 0: the two-stage register kernel (mm_reg2.hip), nn = reg2 x reg2_r2
   unsigned fb_grp_bytes = 0;     // its LDS bytes per wave: two buffers of fb x nn complex points
 };
 

@@ -1,0 +1,215 @@
+// Two register stages for the common non-power-of-two frames: nn = n_fft / 2 = R1 x R2 complex points.
+// Its own translation unit (28 instantiations); mm_any.h carries the launch wrappers for mm_api.hip.
+#include "mm_any.h"
+#include "mm_hb_math.h"
+
+// The textbook 25 ms frame at 16 kHz (400 samples) is 200 = 8 x 25 complex points.  The LDS-resident Stockham passes of
+// stft_any_kernel / stft_anyb_kernel pay three passes of [read, twiddle, butterfly, write] per frame; here the transform
+// is TWO register stages with ONE LDS exchange between them, as the power-of-two kernels have it:
+//   stage 1: Stockham pass of radix R1 straight from global memory -- task (frame, j < R2) loads the sample pairs
+//            j + R2 t (t < R1), applies the window, runs the R1-point DFT in registers and stores its R1 outputs;
+//   stage 2: pass of radix R2 -- lane = (frame, k < R1), FB = 64 / R1 frames per wave at once: R2 strided reads, the
+//            twiddles W_nn^(k t) (loop-invariant per lane: kept in registers), the R2-point DFT, and the outputs go
+//            back to the SAME R2 slots (pass 2 of a two-pass Stockham transform is in place per butterfly);
+//   split:   the pairs (k, nn - k) of all FB frames into registers, then the power rows over the same LDS;
+//   mel:     (filter, frame) pairs, frame fastest, as in stft_anyb_kernel.
+// LDS per wave: FB x FP complex points.  BP = R1 | 1 points between a frame's R2 butterflies (odd: stage 1's b64 stores
+// are conflict-free); FP >= R2 BP with FP = R1 (mod 32): lane (frame, k) of stage 2 then sits on banks 2 lane, 2 lane + 1.
+// Per 1 025 024 frames (BASELINE configs[1] shape, tools/any_time.py), one-frame / batched LDS kernel -> this one:
+// n_fft 400: 1.45 / 1.23 -> 0.67 ms, 800: 2.96 -> 1.12 ms (the n_fft 512 kernel: 0.45).
+template <int R1, int R2>
+struct Reg2Geo {
+  static constexpr int NN = R1 * R2, FB = 64 / R1, NP = NN / 2 + 1;
+  static constexpr int BP = R1 | 1;                                    // butterfly pitch (complex points)
+  static constexpr int FP = R2 * BP + ((R1 % 32) - (R2 * BP) % 32 + 32) % 32;      // frame pitch
+  static constexpr int PPITCH = (NN + 2) | 1;                          // power-row pitch (floats, odd)
+  static constexpr int NPL = (FB * NP + 63) / 64;                      // pairs per lane in the split
+  static constexpr unsigned WAVE_BYTES = FB * FP * 8;
+  static_assert(FP >= R2 * BP && FP % 32 == R1 % 32 && FB * PPITCH * 4 <= (int)WAVE_BYTES && FB >= 1, "layout");
+};
+
+template <int R1, int R2, int MODE>
+__global__ __launch_bounds__(256) void stft_reg2_kernel(AnyParams p) {
+  using G = Reg2Geo<R1, R2>;
+  constexpr int NN = G::NN, FB = G::FB, NP = G::NP, BP = G::BP, FP = G::FP, PPITCH = G::PPITCH, NPL = G::NPL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  char* base = smem + (size_t)grp * G::WAVE_BYTES;
+  float* ctab = reinterpret_cast<float*>(smem + (size_t)4 * G::WAVE_BYTES);
+  for (int i = threadIdx.x; i < p.tab_floats; i += 256) ctab[i] = p.tabpack[i];
+  __syncthreads();
+  const float2* c_win2 = reinterpret_cast<const float2*>(ctab);
+  const float2* c_tw = reinterpret_cast<const float2*>(ctab + p.o_tw);
+  const float2* c_split = reinterpret_cast<const float2*>(ctab + p.o_split);
+  const float* c_melw = ctab + p.o_melw;
+  const int* c_mstart = reinterpret_cast<const int*>(ctab + p.o_mstart);
+  const int* c_mlen = reinterpret_cast<const int*>(ctab + p.o_mlen);
+  const int* c_moff = reinterpret_cast<const int*>(ctab + p.o_moff);
+  hb_c<float>* zA = reinterpret_cast<hb_c<float>*>(base);
+  float* P = reinterpret_cast<float*>(base);
+
+  // stage 2's lane: frame fr2, butterfly k2 (lanes >= FB R1 idle); its R2 - 1 twiddles W_nn^(k2 t) stay in registers
+  // for the whole launch
+  const int fr2 = tid / R1, k2 = tid - fr2 * R1;
+  hb_c<float> tw2[R2 - 1];
+#pragma unroll
+  for (int t = 1; t < R2; ++t) { const float2 w = c_tw[k2 * t]; tw2[t - 1].x = w.x; tw2[t - 1].y = w.y; }
+
+  const int fpb = 4 * p.frames_per_group;
+  const int64_t tiles = (p.n_frames + fpb - 1) / fpb;
+  const int64_t b = blockIdx.x / tiles;
+  const int64_t t0 = (blockIdx.x % tiles) * fpb + (int64_t)grp * p.frames_per_group;
+  const float* a = p.audio + b * p.stride;
+  float vmax = -INFINITY;
+  for (int f0 = 0; f0 < p.frames_per_group; f0 += FB) {
+    const int64_t tb = t0 + f0;
+    if (tb >= p.n_frames) break;                          // wave-uniform
+    const int nf = (int)(p.n_frames - tb < FB ? p.n_frames - tb : FB);
+    const int64_t s_first = tb * p.hop - (p.n_fft >> 1), s_last = (tb + nf - 1) * p.hop - (p.n_fft >> 1);
+    const bool inside = s_first >= 1 && s_last + p.n_fft <= p.n_samples && p.preemph == 0.0f;      // wave-uniform
+    // ---- stage 1: radix R1 from global memory ----
+    for (int tt = tid; tt < nf * R2; tt += 64) {
+      const int fr = tt / R2, j = tt - fr * R2;
+      hb_c<float> v[R1];
+      if (inside) {
+        const float* af = a + s_first + (int64_t)fr * p.hop + 2 * j;
+#pragma unroll
+        for (int t = 0; t < R1; ++t) {
+          const MmAnyFloat2U xv = *reinterpret_cast<const MmAnyFloat2U*>(af + 2 * R2 * t);
+          const float2 w = c_win2[j + R2 * t];
+          v[t].x = xv.x * w.x; v[t].y = xv.y * w.y;
+        }
+      } else {
+        const int64_t s0 = s_first + (int64_t)fr * p.hop + 2 * j;
+#pragma unroll
+        for (int t = 0; t < R1; ++t) {
+          const float2 w = c_win2[j + R2 * t];
+          v[t].x = load_sample(a, s0 + 2 * R2 * t, p.n_samples, p.preemph) * w.x;
+          v[t].y = load_sample(a, s0 + 2 * R2 * t + 1, p.n_samples, p.preemph) * w.y;
+        }
+      }
+      hb_dft<float, R1>(v);
+      hb_c<float>* o = zA + fr * FP + j * BP;
+#pragma unroll
+      for (int u = 0; u < R1; ++u) o[u] = v[hb_perm<R1>(u)];
+    }
+    wave_lds_sync();
+    // ---- stage 2: radix 25, in place ----
+    if (fr2 < nf) {
+      hb_c<float>* zf = zA + fr2 * FP + k2;
+      hb_c<float> v[R2];
+#pragma unroll
+      for (int t = 0; t < R2; ++t) v[t] = zf[t * BP];
+#pragma unroll
+      for (int t = 1; t < R2; ++t) v[t] = hb_mul(v[t], tw2[t - 1]);
+      hb_dft<float, R2>(v);
+#pragma unroll
+      for (int u = 0; u < R2; ++u) zf[u * BP] = v[u];
+    }
+    wave_lds_sync();
+    // ---- real split + power: pairs (k, nn - k) into registers, then the power rows over the same LDS ----
+    // (spectrum bin q of a frame sits at q + (q / R1) (BP - R1))
+    {
+      float pa[NPL], pb[NPL];
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int idx = tid + 64 * i;
+        pa[i] = 0.0f; pb[i] = 0.0f;
+        if (idx < nf * NP) {
+          const int fr = idx / NP, k = idx - fr * NP;
+          const int kb = k ? NN - k : 0;
+          const hb_c<float>* Zf = zA + fr * FP;
+          const hb_c<float> za = Zf[k + (k / R1) * (BP - R1)], zb = Zf[kb + (kb / R1) * (BP - R1)];
+          const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);
+          const float dx = 0.5f * (za.x - zb.x), dy = 0.5f * (za.y + zb.y);
+          const float ox = dy, oy = -dx;                       // -i D
+          const float2 w = c_split[k];
+          const float tx = w.x * ox - w.y * oy, ty = w.x * oy + w.y * ox;
+          const float ar = ex + tx, ai = ey + ty, br = ex - tx, bi = ey - ty;
+          pa[i] = ar * ar + ai * ai;
+          pb[i] = br * br + bi * bi;
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int idx = tid + 64 * i;
+        if (idx < nf * NP) {
+          const int fr = idx / NP, k = idx - fr * NP;
+          P[fr * PPITCH + k] = pa[i];
+          P[fr * PPITCH + NN - k] = pb[i];
+        }
+      }
+    }
+    wave_lds_sync();
+    if (MODE == 0) {
+      for (int fr = 0; fr < nf; ++fr) {
+        float* o = p.out_power + (b * p.n_frames + tb + fr) * p.n_bins;
+        for (int k = tid; k < p.n_bins; k += 64) o[k] = P[fr * PPITCH + k];
+      }
+    } else {
+      const float rnf = 1.0f / (float)nf;
+      for (int idx = tid; idx < nf * p.n_mels; idx += 64) {
+        const int m = (int)(((float)idx + 0.5f) * rnf), fr = idx - m * nf;
+        const float* w = c_melw + c_moff[m];
+        const float* pp = P + fr * PPITCH + c_mstart[m];
+        const int len = c_mlen[m];
+        float acc = 0.0f;
+        int j = 0;
+        for (; j + 4 <= len; j += 4) {
+          const float w0 = w[j], w1 = w[j + 1], w2 = w[j + 2], w3 = w[j + 3];
+          const float q0 = pp[j], q1 = pp[j + 1], q2 = pp[j + 2], q3 = pp[j + 3];
+          acc = fmaf(w0, q0, acc); acc = fmaf(w1, q1, acc); acc = fmaf(w2, q2, acc); acc = fmaf(w3, q3, acc);
+        }
+        for (; j < len; ++j) acc = fmaf(w[j], pp[j], acc);
+        const float db = 10.0f * log10f(fmaxf(p.amin, acc)) - p.db_offset;
+        p.out_logmel[(b * p.n_mels + m) * p.n_frames + tb + fr] = db;
+        vmax = fmaxf(vmax, db);
+      }
+    }
+    wave_lds_sync();
+  }
+  if (MODE == 1) {
+    vmax = wave_max(vmax);
+    if (tid == 0 && vmax > -INFINITY) atomicMax(p.clip_key + b, float_key(vmax));
+  }
+}
+
+// ---- host side ----
+#define MM_REG2_PAIRS(X) X(4, 25) X(8, 25) X(12, 25) X(16, 25) X(20, 25) X(24, 25) X(32, 25) X(40, 25) \
+  X(8, 15) X(16, 15) X(8, 20) X(16, 20) X(24, 20) X(32, 24)
+
+// n_fft = 2 nn: 200, 400, 600, 800, 1000, 1200, 1600, 2000 (R2 = 25); 240, 480 (15); 320, 640, 960 (20); 1536 (24)
+bool reg2_pick(int nn, int* r1, int* r2) {
+#define X(A, B) if (nn == (A) * (B)) { *r1 = A; *r2 = B; return true; }
+  MM_REG2_PAIRS(X)
+#undef X
+  return false;
+}
+
+size_t reg2_lds_bytes(int r1, int r2, int tab_floats) {
+#define X(A, B) if (r1 == A && r2 == B) return 4 * (size_t)Reg2Geo<A, B>::WAVE_BYTES + (size_t)tab_floats * 4;
+  MM_REG2_PAIRS(X)
+#undef X
+  return 0;
+}
+
+int reg2_frames_per_wave(int r1) { const int fb = 64 / r1; return 32 / fb * fb; }
+
+bool reg2_set_attr(int r1, int r2, int bytes) {
+#define X(A, B) if (r1 == A && r2 == B) \
+    return hipFuncSetAttribute((const void*)stft_reg2_kernel<A, B, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
+           hipFuncSetAttribute((const void*)stft_reg2_kernel<A, B, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  MM_REG2_PAIRS(X)
+#undef X
+  return false;
+}
+
+void reg2_launch(int r1, int r2, int mode, dim3 grid, size_t lds, hipStream_t st, const AnyParams& q) {
+#define X(A, B) if (r1 == A && r2 == B) { \
+    if (mode == 0) hipLaunchKernelGGL((stft_reg2_kernel<A, B, 0>), grid, dim3(256), lds, st, q); \
+    else hipLaunchKernelGGL((stft_reg2_kernel<A, B, 1>), grid, dim3(256), lds, st, q); \
+    return; }
+  MM_REG2_PAIRS(X)
+#undef X
+}

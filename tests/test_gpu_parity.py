@@ -607,6 +607,15 @@ _ANY_NFFT = [
     (dict(sr=32000, n_fft=800, win_length=800, hop_length=320, n_mels=64, n_mfcc=20, fmin=50.0, fmax=16000.0), "800 = 16 x 25 complex points: two register stages"),
     (dict(sr=16000, n_fft=800, win_length=400, hop_length=37, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0, preemph=0.97), "800, odd hop, pre-emphasis"),
     (dict(sr=16000, n_fft=400, win_length=400, hop_length=99, n_mels=26, n_mfcc=13, fmin=0.0, fmax=8000.0, preemph=0.95, top_db=30.0), "400, odd hop, pre-emphasis"),
+    (dict(sr=8000, n_fft=200, win_length=200, hop_length=80, n_mels=24, n_mfcc=12, fmin=50.0, fmax=4000.0), "200 = 2 x (4 x 25): two register stages"),
+    (dict(sr=8000, n_fft=240, win_length=240, hop_length=80, n_mels=24, n_mfcc=12, fmin=50.0, fmax=4000.0), "240 = 2 x (8 x 15)"),
+    (dict(sr=16000, n_fft=320, win_length=320, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "320 = 2 x (8 x 20)"),
+    (dict(sr=16000, n_fft=480, win_length=480, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "480 = 2 x (16 x 15)"),
+    (dict(sr=16000, n_fft=640, win_length=640, hop_length=161, n_mels=64, n_mfcc=13, fmin=100.0, fmax=8000.0, preemph=0.97), "640 = 2 x (16 x 20), odd hop, pre-emphasis"),
+    (dict(sr=48000, n_fft=960, win_length=960, hop_length=480, n_mels=80, n_mfcc=20, fmin=100.0, fmax=20000.0), "960 = 2 x (24 x 20)"),
+    (dict(sr=48000, n_fft=1200, win_length=1200, hop_length=480, n_mels=80, n_mfcc=20, fmin=100.0, fmax=20000.0), "1200 = 2 x (24 x 25)"),
+    (dict(sr=44100, n_fft=1600, win_length=1102, hop_length=441, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "1600 = 2 x (32 x 25)"),
+    (dict(sr=48000, n_fft=2000, win_length=1200, hop_length=480, n_mels=80, n_mfcc=20, fmin=100.0, fmax=20000.0, preemph=0.97), "2000 = 2 x (40 x 25), pre-emphasis"),
     (dict(sr=16000, n_fft=600, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "600 = 2^3 3 5^2"),
     (dict(sr=22050, n_fft=1536, win_length=551, hop_length=220, n_mels=64, n_mfcc=20, fmin=0.0, fmax=11025.0), "1536 = 2^9 3"),
     (dict(sr=44100, n_fft=441, win_length=441, hop_length=147, n_mels=30, n_mfcc=12, fmin=50.0, fmax=20000.0), "441 = 3^2 7^2, odd"),
