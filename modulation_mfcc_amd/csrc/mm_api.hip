@@ -977,12 +977,13 @@ struct StftOut {
 // one the in-kernel rFFT covers, and the clips must spread evenly -- a workgroup that gets one clip more than the
 // others sets the launch time, so the uneven case stays on the tile-granular split + separate launches.
 static bool s16_clip_mode_ok(const mm_plan* p, int64_t batch, int n_mod) {
-  if (p->no_fuse_tail || !(n_mod == 512 || n_mod == 1024)) return false;
+  if (p->no_fuse_tail || !(n_mod == 512 || n_mod == 1024 || (n_mod == 2048 && p->rf2k_ok))) return false;
   const int64_t g = p->num_cus;
   if (batch < g) return false;
   const int64_t per = (batch + g - 1) / g;
   if (per > MM_S16_CPW_MAX) return false;                                          // extreme slots [per][16] in LDS
   if ((size_t)p->s16f_red_off + (size_t)per * 128 > MM_LM_LDS_MAX) return false;
+  if (n_mod == 2048 && (size_t)MM_S16_DELTA_OFF((size_t)p->s16f_red_off) + MM_S16_CPW_MAX * 4 > MM_LM_LDS_MAX) return false;
   return per * g * 100 <= batch * 104;          // at most 4 % of idle workgroup time
 }
 
@@ -1176,6 +1177,10 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
             grid = batch < p->num_cus ? batch : p->num_cus;
             lds = std::max((size_t)p->s16f_red_off + (size_t)((batch + grid - 1) / grid) * 128,
                            (size_t)MM_S16_FIN_TAB_OFF + MM_S16_FIN_TAB_BYTES);
+            if (o.n_mod == 2048) {          // the tail runs the 2048-point transform: its lane table rides in q.tw
+              q.tw = (const float2*)p->d_rf2k_lane_tab;
+              lds = std::max(lds, (size_t)MM_S16_DELTA_OFF((size_t)p->s16f_red_off) + MM_S16_CPW_MAX * 4);
+            }
           }
         }
         launch_s16(mode, p->s16_nr, pre, odd, unal, dim3((unsigned)grid), lds, st, q);

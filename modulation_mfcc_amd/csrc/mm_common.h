@@ -187,6 +187,43 @@ __device__ __forceinline__ float mm_empty_level(float amin, float db_offset) {
 #define MM_LM_LDS_MAX 163840     // the CU's whole LDS: what a single workgroup may declare (160 KiB)
 #define MM_DCT_KB 16            // DCT coefficients per accumulator block of the lane <-> frame clamp + DCT kernels
 
+// Clamp fix-up of the fused DCT (dct_fixup_kernel in tile mode, s16_fix_clip in clip mode -- the same arithmetic in the
+// same order, so the two modes agree to the bit).  The fused kernel stored DCT(unclamped rows); the clamped result is
+//   sum_m D[k][m] max(x_m, thr) = DCT(unclamped)[k] + sum_m D[k][m] max(thr - x_m, 0):
+// the correction of ONE frame's coefficients k0 .. k0 + 15 over the stored filters, ascending, into acc.  Only values under
+// the threshold contribute, so a wave whose 64 frames have none for a filter skips its sixteen multiply-adds (adding
+// D * 0 would leave acc as it is: the skip never changes a result) -- a clip with a few dips costs one pass over its
+// log-mel rows instead of a full n_mels x n_mfcc product per frame.  x_of(m): the frame's log-mel value of filter m;
+// ew_of(m0): the "is empty, not stored" bits of filters m0 .. m0 + 31 (m0 a multiple of 32); d_of(m, f): calls f(kk, D[k0 + kk][m]), kk < 16.
+// Returns (wave-uniform) whether anything was added.
+template <typename FX, typename FE, typename FD>
+__device__ __forceinline__ bool mm_clamp_corr(float (&acc)[MM_DCT_KB], int n_mels, float thr, FX x_of, FE ew_of, FD d_of) {
+  bool touched = false;
+#pragma unroll 1
+  for (int m0 = 0; m0 < n_mels; m0 += 32) {
+    // thirty-two loads in flight (the rows come from HBM: a clip's fix-up is a chain of such round trips); the rows of
+    // empty filters were never stored and are not read
+    const unsigned ew = ew_of(m0);
+    float xv[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      xv[j] = 0.0f;
+      if (m0 + j < n_mels && !((ew >> j) & 1u)) xv[j] = x_of(m0 + j);             // (wave-uniform)
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (m0 + j < n_mels && !((ew >> j) & 1u)) {                  // (wave-uniform)
+        const float d = fmaxf(thr - xv[j], 0.0f);
+        if (__ballot(d > 0.0f) != 0ull) {
+          touched = true;
+          d_of(m0 + j, [&](int kk, float dk) { acc[kk] = __builtin_fmaf(dk, d, acc[kk]); });
+        }
+      }
+    }
+  }
+  return touched;
+}
+
 struct RfftParams {
   const float* in;
   int64_t rows, in_len, in_stride;

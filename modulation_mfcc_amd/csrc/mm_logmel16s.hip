@@ -5,4 +5,5 @@
 #include "mm_s16.h"
 #include "mm_fft16.hip.inc"          // f16:: register radix-16 core, Logmel512Params, the P-tile layout
 #include "mm_logmel16w.hip.inc"      // lane-record layout (MM_W16_LT_PITCH), w16_read16
+#include "mm_wpf_core.hip.inc"       // the 2048-point register transform of the clip-mode tail (n_mod 2048)
 #include "mm_logmel16s.hip.inc"

@@ -23,6 +23,9 @@
 #define MM_S16_FIN_REC 24
 #define MM_S16_FIN_TAB_BYTES ((32 * MM_S16_FIN_REC + 15) * 8)
 #define MM_S16_FIN_TAB_OFF (16 * 9216)
+// n_mod 2048: the per-clip add factors (MM_S16_CPW_MAX floats) lie behind the extreme slots and behind the tail's buffers
+#define MM_S16_DELTA_OFF(red_off) (((red_off) + MM_S16_CPW_MAX * 128 > MM_S16_FIN2K_BYTES) ? (red_off) + MM_S16_CPW_MAX * 128 : MM_S16_FIN2K_BYTES)
+#define MM_S16_FIN2K_BYTES 103424   // n_mod 2048: lane table of the 2048-point transform (64 x 116 floats) + 16 x 4.5 KB exchange buffers
 
 struct Logmel512Params;
 // mode 0 power rows | 1 log-mel (+ fused DCT) | (1 with q.out_mod set ->) 2 clip mode; nr = 16-byte staging groups per thread
