@@ -150,7 +150,9 @@ int mm_plan_set_fuse_dct(mm_plan* plan, int on);
  * n_fft 512 staged-sample kernel with its fused DCT takes the call, the trajectory length is 512 or 1024 and
  * `batch` clips spread over the compute units within 4 % (at most 32 per workgroup); 0 = the separate launches.
  * mm_plan_set_fuse_tail(plan, 0) pins the separate launches (A/B measurements, cross-checks; returns the previous
- * setting; default on).  The same switch selects the device form of mm_mfcc_change_f64 (on: the clip-resident
+ * setting; default on = 1).  2 widens clip mode to 2048-point trajectories (1025 .. 2048 frames per clip: the 2048-point
+ * transform at the end of the launch) and to mm_mfcc_f32 on plans with empty mel filters (their add inside the launch):
+ * faster when no clip clamps, slower when a few do (one workgroup pays a clip's whole fix-up) -- see DESIGN.md 4.3.  The same switch selects the device form of mm_mfcc_change_f64 (on: the clip-resident
  * single launch; off: the time-major launches). */
 int mm_plan_fused_tail(const mm_plan* plan, int64_t batch, int64_t n_samples);
 int mm_plan_set_fuse_tail(mm_plan* plan, int on);

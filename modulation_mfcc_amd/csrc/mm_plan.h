@@ -71,6 +71,7 @@ struct mm_plan {
   int variant;                     // mm_plan_set_variant: 0 = automatic
   int no_fuse;                     // mm_plan_set_fuse_dct(0): always run the separate clamp + DCT kernel
   int no_fuse_tail;                // mm_plan_set_fuse_tail(0): mm_mfcc_modspec_f32 always runs its separate launches
+  int fuse_tail_wide;              // mm_plan_set_fuse_tail(2): clip mode also for 2048-point trajectories and for mm_mfcc_f32 (empty filters)
   unsigned s16f_red_off;           // clip mode: LDS offset of the per-wave clip max / min slots
 
   float* d_window_e;                       // n_fft < 512 embedded in the 512-point kernels: window centred in 512

@@ -23,8 +23,10 @@
 #define MM_S16_FIN_REC 24
 #define MM_S16_FIN_TAB_BYTES ((32 * MM_S16_FIN_REC + 15) * 8)
 #define MM_S16_FIN_TAB_OFF (16 * 9216)
-// n_mod 2048: the per-clip add factors (MM_S16_CPW_MAX floats) lie behind the extreme slots and behind the tail's buffers
-#define MM_S16_DELTA_OFF(red_off) (((red_off) + MM_S16_CPW_MAX * 128 > MM_S16_FIN2K_BYTES) ? (red_off) + MM_S16_CPW_MAX * 128 : MM_S16_FIN2K_BYTES)
+// clip mode, plans with empty filters: the per-clip add factors (a float per clip of the workgroup) lie behind the extreme
+// slots of the launch's largest workgroup (clips_max x 128 B) and, at n_mod 2048, behind the 2048-point tail's buffers
+#define MM_S16_DELTA_OFF(red_off, clips_max, n_mod)                                                             \
+  (((n_mod) == 2048 && (red_off) + (clips_max) * 128 < MM_S16_FIN2K_BYTES) ? MM_S16_FIN2K_BYTES : (red_off) + (clips_max) * 128)
 #define MM_S16_FIN2K_BYTES 103424   // n_mod 2048: lane table of the 2048-point transform (64 x 116 floats) + 16 x 4.5 KB exchange buffers
 
 struct Logmel512Params;

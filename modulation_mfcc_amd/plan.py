@@ -242,8 +242,10 @@ class MfccPlan:
 
     def set_fuse_tail(self, on=True):
         """on=False pins the separate launches for mfcc_modspec() (default: one launch where the plan can) and the
-        time-major kernels for mfcc_change() (default: the clip-resident single launch); returns the previous setting."""
-        return bool(self._lib.mm_plan_set_fuse_tail(self._h, 1 if on else 0))
+        time-major kernels for mfcc_change() (default: the clip-resident single launch); on=2 widens the one-launch path to
+        2048-point trajectories and to mfcc() on plans with empty mel filters (opt-in: include/modmfcc.h); returns the
+        previous setting (0 / 1 / 2)."""
+        return self._lib.mm_plan_set_fuse_tail(self._h, 2 if on == 2 else (1 if on else 0))
 
     def force_generic(self, on=True):
         return self._lib.mm_plan_force_generic(self._h, 1 if on else 0)

@@ -774,8 +774,8 @@ def test_headline_config_through_the_headline_entry_point(gpu):
 @pytest.mark.parametrize("n,B", [(100000, 512), (64321, 256), (51300, 300)])
 def test_clip_mode_with_a_2048_point_trajectory(n, B, gpu):
     """The reference's own default call (10 kHz, win 250, hop 50, 128 mel: script/main.py:732-748) as a batch: ten seconds
-    are 2001 frames, so the trajectory rFFT is 2048 points -- clip mode runs it inside the launch on the 2048-point
-    register transform (s16_fin_modspec_2k).  MFCC bit-equal to the separate launches and the spectrum bit-equal to the
+    are 2001 frames, so the trajectory rFFT is 2048 points -- clip mode (opt-in for this length: set_fuse_tail(2)) runs it
+    inside the launch on the 2048-point register transform (s16_fin_modspec_2k).  MFCC bit-equal to the separate launches and the spectrum bit-equal to the
     separate rfft_wpf_kernel<4> (the same arithmetic on the same rows); spot clips of every kind against the oracle;
     Parseval on every trajectory.  Ragged lengths (T 1287, 1027: just above 1024) as well; a batch that does not spread
     evenly over the workgroups (300) takes the separate launches and agrees."""
@@ -789,15 +789,17 @@ def test_clip_mode_with_a_2048_point_trajectory(n, B, gpu):
     host = np.stack([O.synth_clip(100 + i, n, 10000, kinds[i % 5]) if i < 10 else
                      (0.05 * rng.standard_normal(n)).astype(np.float32) for i in range(B)])
     audio = _dev(host, gpu)
-    assert plan.fused_tail(B, n) == (B != 300)
-    m1, s1 = plan.mfcc_modspec(audio)
-    assert m1.shape == (B, 13, T) and s1.shape == (B, 13, 1025)
-    prev = plan.set_fuse_tail(False)
+    assert not plan.fused_tail(B, n)                      # opt-in: set_fuse_tail(2)
+    m0, s0 = plan.mfcc_modspec(audio)
+    prev = plan.set_fuse_tail(2)
     try:
-        assert not plan.fused_tail(B, n)
-        m0, s0 = plan.mfcc_modspec(audio)
+        assert plan.fused_tail(B, n) == (B != 300)
+        m1, s1 = plan.mfcc_modspec(audio)
+        mc = plan.mfcc(audio)                             # clip mode without a spectrum (the empty filters' add in the launch)
     finally:
         plan.set_fuse_tail(prev)
+    assert m1.shape == (B, 13, T) and s1.shape == (B, 13, 1025)
+    assert torch.equal(mc, m0)
     assert torch.equal(m1, m0), float((m1 - m0).abs().max())
     assert torch.equal(torch.view_as_real(s1), torch.view_as_real(s0))
     ocfg = O.OracleConfig(**kw)
@@ -860,6 +862,15 @@ def test_empty_filters_are_handled_analytically(kw, n, what, gpu):
     assert bool(torch.isfinite(m).all())
     for i in (0, 1, 2, 3, 4, B - 1):
         mfcc_close(m[i].cpu().numpy(), O.mfcc(audio[i].cpu().numpy(), ocfg), f"{what}: clip {i}")
+    # opt-in (set_fuse_tail(2)): mm_mfcc_f32 in clip mode -- the add and the fix-up inside the launch -- gives the bits of
+    # the tile kernel + dct_fixup_kernel
+    prev = plan.set_fuse_tail(2)
+    try:
+        mt = plan.mfcc(audio)
+    finally:
+        plan.set_fuse_tail(prev)
+    assert torch.equal(m, mt), float((m - mt).abs().max())
+    assert torch.equal(plan.mfcc(audio[:77]), m[:77])
     prev = plan.set_fuse_dct(False)
     try:
         assert not plan.fused_dct
