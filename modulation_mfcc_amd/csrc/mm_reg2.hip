@@ -66,32 +66,44 @@ __global__ __launch_bounds__(256) void stft_reg2_kernel(AnyParams p) {
     if (tb >= p.n_frames) break;                          // wave-uniform
     const int nf = (int)(p.n_frames - tb < FB ? p.n_frames - tb : FB);
     const int64_t s_first = tb * p.hop - (p.n_fft >> 1), s_last = (tb + nf - 1) * p.hop - (p.n_fft >> 1);
-    const bool inside = s_first >= 1 && s_last + p.n_fft <= p.n_samples && p.preemph == 0.0f;      // wave-uniform
-    // ---- stage 1: radix R1 from global memory ----
-    for (int tt = tid; tt < nf * R2; tt += 64) {
-      const int fr = tt / R2, j = tt - fr * R2;
-      hb_c<float> v[R1];
-      if (inside) {
-        const float* af = a + s_first + (int64_t)fr * p.hop + 2 * j;
-#pragma unroll
-        for (int t = 0; t < R1; ++t) {
-          const MmAnyFloat2U xv = *reinterpret_cast<const MmAnyFloat2U*>(af + 2 * R2 * t);
-          const float2 w = c_win2[j + R2 * t];
-          v[t].x = xv.x * w.x; v[t].y = xv.y * w.y;
-        }
-      } else {
+    // (s_first >= 1: the pre-emphasis tap of the batch's first sample)
+    const bool inside = s_first >= 1 && s_last + p.n_fft <= p.n_samples;      // wave-uniform
+    const float pre = p.preemph;
+    // ---- stage 1: radix R1 from global memory (one task loop per way of loading: the choice is wave-uniform) ----
+    auto stage1 = [&](auto load_pair) {
+      for (int tt = tid; tt < nf * R2; tt += 64) {
+        const int fr = tt / R2, j = tt - fr * R2;
+        hb_c<float> v[R1];
         const int64_t s0 = s_first + (int64_t)fr * p.hop + 2 * j;
 #pragma unroll
         for (int t = 0; t < R1; ++t) {
           const float2 w = c_win2[j + R2 * t];
-          v[t].x = load_sample(a, s0 + 2 * R2 * t, p.n_samples, p.preemph) * w.x;
-          v[t].y = load_sample(a, s0 + 2 * R2 * t + 1, p.n_samples, p.preemph) * w.y;
+          const float2 x = load_pair(s0 + 2 * R2 * t);
+          v[t].x = x.x * w.x; v[t].y = x.y * w.y;
         }
-      }
-      hb_dft<float, R1>(v);
-      hb_c<float>* o = zA + fr * FP + j * BP;
+        hb_dft<float, R1>(v);
+        hb_c<float>* o = zA + fr * FP + j * BP;
 #pragma unroll
-      for (int u = 0; u < R1; ++u) o[u] = v[hb_perm<R1>(u)];
+        for (int u = 0; u < R1; ++u) o[u] = v[hb_perm<R1>(u)];
+      }
+    };
+    if (inside && pre == 0.0f) {
+      stage1([&](int64_t s) {
+        const MmAnyFloat2U xv = *reinterpret_cast<const MmAnyFloat2U*>(a + s);
+        return make_float2(xv.x, xv.y);
+      });
+    } else if (inside) {
+      // pre-emphasis y[n] - a y[n-1]: one more 4-byte load per pair; rounded product, then the subtraction (load_sample's
+      // arithmetic)
+      stage1([&](int64_t s) {
+        const float xm = a[s - 1];
+        const MmAnyFloat2U xv = *reinterpret_cast<const MmAnyFloat2U*>(a + s);
+        return make_float2(xv.x - __fmul_rn(pre, xm), xv.y - __fmul_rn(pre, xv.x));
+      });
+    } else {
+      stage1([&](int64_t s) {
+        return make_float2(load_sample(a, s, p.n_samples, pre), load_sample(a, s + 1, p.n_samples, pre));
+      });
     }
     wave_lds_sync();
     // ---- stage 2: radix 25, in place ----
