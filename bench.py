@@ -312,6 +312,17 @@ def time_next_rows(torch, dev):
                                                    "and direction through a float64 workspace)")
     out["N3_envelope_iir_filter_256x160000"]["implementation_bytes"] = 256 * 160000 * (4 + 8 + 8 + 8)
     del env
+    # a typed n_fft (the reference's dialog passes what the user types: script/config_dialog.py:141,610): BASELINE
+    # configs[1]'s batch with 400- and 800-sample frames on the two-stage register kernel (mm_reg2.hip)
+    x16 = 0.1 * torch.randn((1024, 160000), device=dev)
+    for nf_ in (400, 800):
+        pl_ = MfccPlan(MfccConfig(**dict(C16K, n_fft=nf_)))
+        o_ = torch.empty((1024, 13, 1001), device=dev)
+        ms = t(lambda: pl_.mfcc(x16, out=o_))
+        out[f"typed_n_fft_{nf_}_1024x160000"] = hbm(ms, 1024 * 1001 * (4 * 160 + 4 * 13), "unique audio in + MFCC out (SURVEY 8(d)); "
+                                                    "compute-bound like the n_fft 512 kernel (c2 in this record)")
+        del pl_, o_
+    del x16
     x44 = torch.randn((256, 441000), device=dev)
     ms = t(lambda: audio_io.resample_batch(x44, 44100, 16000))
     L, M = audio_io.resample_ratio(44100, 16000)
