@@ -11,4 +11,4 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 100 --warmup 50 --no-cpu --no-check "$@" > $out/bench_trace.json 2> $out/trace.log || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-check --no-extra "$@" > $out/bench_fetch.json 2> $out/fetch.log || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-check --no-extra "$@" > $out/bench_write.json 2> $out/write.log || exit 1
-find $out -name "*.csv" | head -20
+find $out -name "*.csv" | sort | sed -n 1,20p
