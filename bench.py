@@ -294,6 +294,15 @@ def time_next_rows(torch, dev):
     ms = t(lambda: plan.mfcc_change(m1, sos1, sos1))
     out["N1_change_tail_one_recording_1x13x300001"] = hbm(ms, K * 300001 * 4 + 300001 * 8, "MFCC rows in (f32) + change curve out (f64)")
     del m1
+    # row A8 beyond 8192 frames per clip (mm_hilbert_rfft_f32): the trajectories of ONE recording at the reference's
+    # default 1 ms step -- ten seconds (10 001 frames -> 16 384 points) and five minutes (300 001 -> 524 288)
+    for T_, nm_ in ((10001, 16384), (300001, 524288)):
+        tr_ = torch.randn((K, T_), device=dev)
+        o_ = torch.empty((K, nm_ // 2 + 1), dtype=torch.complex64, device=dev)
+        ms = t(lambda: calc.rfft_rows_long(tr_, nm_, out=o_))
+        out[f"A8_long_trajectories_13x{T_}"] = hbm(ms, K * (4 * T_ + 8 * (nm_ // 2 + 1)), "trajectories in + half spectra out "
+                                                   f"(n_mod {nm_}: a complex transform of the zero-padded real rows in global memory)")
+        del tr_, o_
     x = torch.randn((256, 160000), device=dev)
     ms = t(lambda: rms_batch(x, 400, 160, True))
     out["N3_rms_256x160000"] = hbm(ms, 256 * 160000 * 4 + 256 * 1001 * 4, "samples in + envelope out")

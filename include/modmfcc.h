@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 122 /* 0.3.2 */
+#define MM_VERSION 123 /* 0.3.3 */
 
 typedef enum mm_status {
   MM_OK = 0,
@@ -76,7 +76,7 @@ typedef struct mm_config {
   float top_db;       /* 80; < 0 disables the per-clip clamp                                  */
   float amin;         /* 1e-10                                                                */
   int32_t center;     /* must be 1 (librosa center=True, pad_mode='constant')                 */
-  int32_t n_mod_fft;  /* trajectory rFFT length (<= 8192); 0 = next power of two >= n_frames  */
+  int32_t n_mod_fft;  /* trajectory rFFT length; 0 = next power of two >= n_frames (> 8192: mm_hilbert_rfft_f32) */
 } mm_config;
 
 typedef struct mm_plan mm_plan;
@@ -296,6 +296,14 @@ int64_t mm_hilbert_fft_size(const mm_hilbert* h);
 size_t mm_hilbert_workspace_bytes(const mm_hilbert* h, int64_t rows);
 int mm_hilbert_envelope(mm_hilbert* h, const void* d_x, int64_t rows, int64_t x_stride, void* d_env,
                         int64_t env_stride, void* d_workspace, size_t ws_bytes, void* stream);
+/* rFFT of real float32 rows zero-padded to the plan's length n (a plan of dtype 0 whose length is even and 2 / 3 / 5 / 7-
+ * smooth, i.e. mm_hilbert_fft_size() == n): d_x [rows][x_stride] with n_valid <= n samples each -> d_out complex64
+ * [rows][n / 2 + 1] -- the trajectory rFFT (np.fft.rfft(mfcc, n, axis=-1), row A8 of the hot path) for clips with more
+ * than 8192 frames, which mm_modspec_f32 does not take: one recording at the reference's default 1 ms step
+ * (script/mfcc.py:296) is 10 001 frames per ten seconds.  rows <= 65535 per call; asynchronous on `stream`. */
+size_t mm_hilbert_rfft_workspace_bytes(const mm_hilbert* h, int64_t rows);
+int mm_hilbert_rfft_f32(mm_hilbert* h, const float* d_x, int64_t rows, int64_t x_stride, int64_t n_valid, float* d_out,
+                        void* d_ws, size_t ws_bytes, void* stream);
 
 /* Input side (row N4): what librosa.load(path, sr=sigSr, mono=False) does before the hot path
  * (script/mfcc.py:284,373).

@@ -115,6 +115,8 @@ PROTOTYPES = {
     "mm_hilbert_fft_size": (_i64, [_vp]),
     "mm_hilbert_workspace_bytes": (C.c_size_t, [_vp, _i64]),
     "mm_hilbert_envelope": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, C.c_size_t, _vp]),
+    "mm_hilbert_rfft_workspace_bytes": (C.c_size_t, [_vp, _i64]),
+    "mm_hilbert_rfft_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, C.c_size_t, _vp]),
     "mm_pcm_decode_f32": (C.c_int, [_vp, C.c_int32, C.c_int32, _i64, _vp, _i64, _vp]),
     "mm_resample_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, C.c_int32, C.c_int32, C.c_int32, _i64, _vp, _i64, _vp]),
     "mm_resample_banded_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -49,6 +49,52 @@ class _HilbertPlan:
             pass
 
 
+def _hilbert_plan(n, code, device):
+    """The cached mm_hilbert handle of (length, dtype code, device) -- LRU of HILBERT_MAX_PLANS lengths."""
+    key = (int(n), int(code), str(device))
+    if key in _HILBERT_PLANS:
+        _HILBERT_PLANS.move_to_end(key)
+    else:
+        import torch
+        while len(_HILBERT_PLANS) >= HILBERT_MAX_PLANS:      # files of many different lengths: bounded table memory
+            _, old = _HILBERT_PLANS.popitem(last=False)
+            torch.cuda.synchronize(device)                    # nothing in flight may still read the tables
+            del old
+        _HILBERT_PLANS[key] = _HilbertPlan(int(n), int(code), device)
+    return _HILBERT_PLANS[key]
+
+
+def rfft_rows_long(x, n_fft, out=None):
+    """np.fft.rfft(x, n_fft, axis=-1) of float32 device rows [R, T] (T <= n_fft, n_fft even and 2 / 3 / 5 / 7-smooth, in
+    practice a power of two) -> complex64 [R, n_fft / 2 + 1]: the library's Stockham FFT in global memory
+    (mm_hilbert_rfft_f32) -- the trajectory rFFT (row A8) of clips with more than 8192 frames, e.g. one recording at the
+    reference's default 1 ms step (script/mfcc.py:296).  Rows are taken in chunks that bound the workspace."""
+    import torch
+    from . import _lib
+    if not (_is_device_tensor(x) and x.dtype == torch.float32 and x.dim() == 2):
+        raise TypeError("x must be a float32 CUDA(HIP) tensor [rows, T]")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, T = x.shape
+    n_fft = int(n_fft)
+    if T < 1 or T > n_fft:
+        raise ValueError("need 1 <= T <= n_fft")
+    if out is None:
+        out = torch.empty((rows, n_fft // 2 + 1), dtype=torch.complex64, device=x.device)
+    plan = _hilbert_plan(n_fft, 0, x.device)
+    lib = _lib.load()
+    per_row = int(lib.mm_hilbert_rfft_workspace_bytes(plan.h, 1))
+    chunk = int(max(1, min(rows, 65535, HILBERT_WS_BYTES // max(per_row, 1))))
+    ws = torch.empty(int(lib.mm_hilbert_rfft_workspace_bytes(plan.h, chunk)), dtype=torch.uint8, device=x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    with torch.cuda.device(x.device):
+        for r0 in range(0, rows, chunk):
+            r = min(chunk, rows - r0)
+            _lib.check(lib.mm_hilbert_rfft_f32(plan.h, x[r0:].data_ptr(), r, x.stride(0), T, out[r0:].data_ptr(),
+                                               ws.data_ptr(), ws.numel(), stream), "mm_hilbert_rfft_f32")
+    return out
+
+
 def hilbert_envelope_batch(x):
     """|scipy.signal.hilbert(x)| along the last axis of a CUDA(HIP) tensor ([n] or [B, n], float32 or float64)
     on the device, in scipy's arithmetic: DFT of length N = len(x) in the input's precision, negative
@@ -74,16 +120,7 @@ def hilbert_envelope_batch(x):
     if n == 0 or rows == 0:
         return out[0] if squeeze else out
     code = 0 if x.dtype == torch.float32 else 1
-    key = (n, code, str(x.device))
-    if key in _HILBERT_PLANS:
-        _HILBERT_PLANS.move_to_end(key)
-    else:
-        while len(_HILBERT_PLANS) >= HILBERT_MAX_PLANS:      # files of many different lengths: bounded table memory
-            _, old = _HILBERT_PLANS.popitem(last=False)
-            torch.cuda.synchronize(x.device)                  # nothing in flight may still read the tables
-            del old
-        _HILBERT_PLANS[key] = _HilbertPlan(n, code, x.device)
-    plan = _HILBERT_PLANS[key]
+    plan = _hilbert_plan(n, code, x.device)
     lib = _lib.load()
     # two clips share one complex transform: calls of an even number of clips, sized by what a PAIR needs
     per_pair = int(lib.mm_hilbert_workspace_bytes(plan.h, 2))

@@ -236,7 +236,9 @@ int32_t mm_mod_fft_len(const mm_config* c, int64_t n_frames) {
   if (c->n_mod_fft) return c->n_mod_fft >= n_frames ? c->n_mod_fft : MM_ERR_INVALID_ARG;
   int64_t n = 32;
   while (n < n_frames) n *= 2;
-  return n <= 8192 ? (int32_t)n : MM_ERR_UNSUPPORTED;   // trajectory rFFT: up to 8192 frames per clip
+  // (up to 8192 points: mm_modspec_f32 / the fused tail; beyond: mm_hilbert_rfft_f32 -- the caller's choice, the length
+  // is the same rule)
+  return n <= ((int64_t)1 << 24) ? (int32_t)n : MM_ERR_UNSUPPORTED;
 }
 
 int mm_build_window(const mm_config* c, float* out) {
@@ -1348,6 +1350,7 @@ int mm_mfcc_f32(mm_plan* p, const float* d_audio, int64_t batch, int64_t n_sampl
 
 static int launch_rfft(mm_plan* p, const float* d_in, int64_t rows, int64_t in_len, int64_t in_stride,
                        int n, float* d_out, hipStream_t st) {
+  if (n > 8192) return MM_ERR_UNSUPPORTED;      // longer trajectories: mm_hilbert_rfft_f32 (a transform in global memory)
   RfftParams q;
   q.in = d_in; q.rows = rows; q.in_len = in_len; q.in_stride = in_stride; q.n = n;
   q.log2nc = ilog2(n) - 1; q.rows_per_wave = 4; q.tw = p->d_tw; q.out = d_out;

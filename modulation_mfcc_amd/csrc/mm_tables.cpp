@@ -30,7 +30,7 @@ int validate(const mm_config* c) {
   if (!(c->amin > 0.0f)) return MM_ERR_INVALID_ARG;
   if (c->center != 1) return MM_ERR_UNSUPPORTED;
   if (c->n_mod_fft != 0 &&
-      (c->n_mod_fft < 32 || c->n_mod_fft > 8192 || (c->n_mod_fft & (c->n_mod_fft - 1))))
+      (c->n_mod_fft < 32 || c->n_mod_fft > (1 << 24) || (c->n_mod_fft & (c->n_mod_fft - 1))))
     return MM_ERR_UNSUPPORTED;
   return MM_OK;
 }

@@ -285,6 +285,9 @@ class MfccPlan:
             out_mod = torch.empty((B, self.cfg.n_mfcc, nm // 2 + 1), dtype=torch.complex64, device=self.device)
         else:
             self._check_out(out_mod, (B, self.cfg.n_mfcc, nm // 2 + 1), torch.complex64, "modspec")
+        if nm > 8192:
+            self.mfcc(audio, out=out)
+            return out, self.modspec(out, out=out_mod)
         ws = self.workspace(B, n)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.mm_mfcc_modspec_f32(self._h, audio.data_ptr(), B, n, audio.stride(0), out.data_ptr(),
@@ -346,6 +349,14 @@ class MfccPlan:
         n = self.cfg.mod_fft_len(T)
         if mfcc.device != self.device:
             raise ValueError(f"mfcc is on {mfcc.device}, the plan on {self.device}")
+        if n > 8192:
+            # more than 8192 frames per clip (one recording at the reference's 1 ms step): the transform in global memory
+            from .calc import rfft_rows_long
+            if out is not None:
+                self._check_out(out, (B, self.cfg.n_mfcc, n // 2 + 1), torch.complex64, "modspec")
+            res = rfft_rows_long(mfcc.reshape(B * self.cfg.n_mfcc, T), n,
+                                 None if out is None else out.reshape(B * self.cfg.n_mfcc, n // 2 + 1))
+            return res.reshape(B, self.cfg.n_mfcc, n // 2 + 1) if out is None else out
         if out is None:
             out = torch.empty((B, self.cfg.n_mfcc, n // 2 + 1), dtype=torch.complex64,
                               device=self.device)

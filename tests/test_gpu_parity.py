@@ -818,6 +818,47 @@ def test_clip_mode_with_a_2048_point_trajectory(n, B, gpu):
     assert torch.allclose(e_time, e_freq, rtol=1e-4)
 
 
+def test_modulation_spectrum_of_long_trajectories(gpu):
+    """Row A8 beyond 8192 frames per clip -- what the reference's own default step makes of a recording (tStep = 0.001,
+    script/mfcc.py:296: 10 001 frames per ten seconds; a one-minute file: 60 001): mm_modspec_f32 stops at 8192 points,
+    MfccPlan.modspec / mfcc_modspec hand longer trajectories to the Stockham FFT in global memory (mm_hilbert_rfft_f32:
+    16 384 = 256 x 64 and 65 536 = 256 x 256 points).  Against np.fft.rfft in float64, Parseval, and the short path on
+    the same rows (a trajectory cut to 8000 frames and transformed at n_mod_fft = 16384 through both)."""
+    import torch
+    from modulation_mfcc_amd import calc
+    kw = dict(sr=10000, n_fft=512, win_length=250, hop_length=10, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0)
+    plan = _plan(kw)
+    for secs, B in ((10.0, 3), (60.0, 1)):
+        n = int(secs * 10000)
+        T = 1 + n // 10
+        nm = plan.cfg.mod_fft_len(T)
+        assert nm == (16384 if secs == 10.0 else 65536)
+        host = np.stack([O.synth_clip(40 + i, n, 10000, ("am", "noise", "quiet_tail")[i % 3]) for i in range(B)])
+        m, s = plan.mfcc_modspec(_dev(host, gpu))
+        assert m.shape == (B, 13, T) and s.shape == (B, 13, nm // 2 + 1)
+        assert torch.equal(m, plan.mfcc(_dev(host, gpu)))
+        mh = m.cpu().numpy()
+        want = np.fft.rfft(mh.astype(np.float64), n=nm, axis=-1)
+        got = s.cpu().numpy()
+        scale = np.abs(want).max(axis=-1, keepdims=True)
+        assert (np.abs(got - want) <= 2e-6 * scale).all(), float((np.abs(got - want) / scale).max())
+        e_time = (mh.astype(np.float64) ** 2).sum(-1)
+        w = np.full(nm // 2 + 1, 2.0); w[0] = w[-1] = 1.0
+        e_freq = ((np.abs(got.astype(np.complex128)) ** 2) * w).sum(-1) / nm
+        np.testing.assert_allclose(e_freq, e_time, rtol=1e-4)
+    # the two transforms agree where both apply: 8000 frames at 8192 points (mm_modspec_f32) and at 16384 (long path)
+    rows = torch.randn((5, 8000), device=gpu)
+    long16 = calc.rfft_rows_long(rows, 16384).cpu().numpy()
+    w16 = np.fft.rfft(rows.cpu().numpy().astype(np.float64), n=16384, axis=-1)
+    assert np.abs(long16 - w16).max() <= 2e-6 * np.abs(w16).max()
+    # ragged T, many rows (chunked workspace), an output buffer of the caller
+    rows = torch.randn((300, 9001), device=gpu)
+    out = torch.empty((300, 8193), dtype=torch.complex64, device=gpu)
+    calc.rfft_rows_long(rows, 16384, out=out)
+    w = np.fft.rfft(rows.cpu().numpy().astype(np.float64), n=16384, axis=-1)
+    assert np.abs(out.cpu().numpy() - w).max() <= 2e-6 * np.abs(w).max()
+
+
 _EMPTY_CFGS = [
     # (cfg, n_samples, what)
     (dict(sr=10000, n_fft=512, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), 50000,
