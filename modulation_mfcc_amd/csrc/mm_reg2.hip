@@ -16,7 +16,9 @@
 // LDS per wave: FB x FP complex points.  BP = R1 | 1 points between a frame's R2 butterflies (odd: stage 1's b64 stores
 // are conflict-free); FP >= R2 BP with FP = R1 (mod 32): lane (frame, k) of stage 2 then sits on banks 2 lane, 2 lane + 1.
 // Per 1 025 024 frames (BASELINE configs[1] shape, tools/any_time.py), one-frame / batched LDS kernel -> this one:
-// n_fft 400: 1.45 / 1.23 -> 0.67 ms, 800: 2.96 -> 1.12 ms (the n_fft 512 kernel: 0.45).
+// n_fft 400: 1.45 / 1.23 -> 0.62 ms, 800: 2.96 -> 1.12 ms (the n_fft 512 kernel: 0.45).  __launch_bounds__(256, 2): two
+// workgroups per CU are what the LDS allows, so the register allocation must not take more than half the file (first-stage
+// radix 32 / 40 had drifted to 257 - 265 registers, i.e. ONE workgroup per CU: n_fft 1600 4.42 -> 2.41 ms, 2000 7.4 -> 4.4).
 template <int R1, int R2>
 struct Reg2Geo {
   static constexpr int NN = R1 * R2, FB = 64 / R1, NP = NN / 2 + 1;
@@ -25,11 +27,20 @@ struct Reg2Geo {
   static constexpr int PPITCH = (NN + 2) | 1;                          // power-row pitch (floats, odd)
   static constexpr int NPL = (FB * NP + 63) / 64;                      // pairs per lane in the split
   static constexpr unsigned WAVE_BYTES = FB * FP * 8;
+  // prefetch of the next batch's sample pairs into registers: first-stage radix 4 / 8 / 12 (at most 32 pairs per lane).
+  // Same-box A/B against the kernel without it (ms per 1 025 024 frames): n_fft 200 0.457 -> 0.417, 240 0.347 -> 0.331,
+  // 320 0.552 -> 0.507, 400 0.658 -> 0.617, 600 0.922 -> 0.911; radix 16 gains 1.5 % (640, 800) or loses (480: 0.58 ->
+  // 0.72, its twiddles then come from LDS in every batch), radix 24 loses 3 %: off from 16 up.
+#ifdef MM_REG2_NO_PF
+  static constexpr bool PF = false;
+#else
+  static constexpr bool PF = ((FB * R2 + 63) / 64) * R1 <= 32 && R1 <= 12;
+#endif
   static_assert(FP >= R2 * BP && FP % 32 == R1 % 32 && FB * PPITCH * 4 <= (int)WAVE_BYTES && FB >= 1, "layout");
 };
 
 template <int R1, int R2, int MODE>
-__global__ __launch_bounds__(256) void stft_reg2_kernel(AnyParams p) {
+__global__ __launch_bounds__(256, 2) void stft_reg2_kernel(AnyParams p) {
   using G = Reg2Geo<R1, R2>;
   constexpr int NN = G::NN, FB = G::FB, NP = G::NP, BP = G::BP, FP = G::FP, PPITCH = G::PPITCH, NPL = G::NPL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -51,9 +62,15 @@ __global__ __launch_bounds__(256) void stft_reg2_kernel(AnyParams p) {
   // stage 2's lane: frame fr2, butterfly k2 (lanes >= FB R1 idle); its R2 - 1 twiddles W_nn^(k2 t) stay in registers
   // for the whole launch
   const int fr2 = tid / R1, k2 = tid - fr2 * R1;
-  hb_c<float> tw2[R2 - 1];
+  // PF: the next batch's sample pairs are prefetched into registers (below); the twiddles then come from LDS in every
+  // batch instead of living in 2 (R2 - 1) registers -- both together do not fit two waves per SIMD
+  constexpr int NR1 = (FB * R2 + 63) / 64;
+  constexpr bool PF = G::PF;
+  hb_c<float> tw2[PF ? 1 : R2 - 1];
+  if constexpr (!PF) {
 #pragma unroll
-  for (int t = 1; t < R2; ++t) { const float2 w = c_tw[k2 * t]; tw2[t - 1].x = w.x; tw2[t - 1].y = w.y; }
+    for (int t = 1; t < R2; ++t) { const float2 w = c_tw[k2 * t]; tw2[t - 1].x = w.x; tw2[t - 1].y = w.y; }
+  }
 
   const int fpb = 4 * p.frames_per_group;
   const int64_t tiles = (p.n_frames + fpb - 1) / fpb;
@@ -61,14 +78,45 @@ __global__ __launch_bounds__(256) void stft_reg2_kernel(AnyParams p) {
   const int64_t t0 = (blockIdx.x % tiles) * fpb + (int64_t)grp * p.frames_per_group;
   const float* a = p.audio + b * p.stride;
   float vmax = -INFINITY;
-  for (int f0 = 0; f0 < p.frames_per_group; f0 += FB) {
-    const int64_t tb = t0 + f0;
-    if (tb >= p.n_frames) break;                          // wave-uniform
-    const int nf = (int)(p.n_frames - tb < FB ? p.n_frames - tb : FB);
-    const int64_t s_first = tb * p.hop - (p.n_fft >> 1), s_last = (tb + nf - 1) * p.hop - (p.n_fft >> 1);
+  const float pre = p.preemph;
+  // The NEXT batch's sample pairs are requested while this batch is in its second stage, split and mel sweep: a batch was
+  // NR1 rounds of [R1 loads, wait, butterfly] -- ~2 us of memory latency each, most of the ~11 us a batch of eight
+  // 400-sample frames took.  NR1 x R1 pairs in registers (at most 40); batches inside the clip without pre-emphasis only.
+  float2 pf[PF ? NR1 : 1][PF ? R1 : 1];
+  bool have_pf = false;
+  auto batch_geo = [&](int f0, int64_t& tb, int& nf, int64_t& s_first, bool& inside) {
+    tb = t0 + f0;
+    nf = (int)(p.n_frames - tb < FB ? p.n_frames - tb : FB);
+    s_first = tb * p.hop - (p.n_fft >> 1);
+    const int64_t s_last = (tb + nf - 1) * p.hop - (p.n_fft >> 1);
     // (s_first >= 1: the pre-emphasis tap of the batch's first sample)
-    const bool inside = s_first >= 1 && s_last + p.n_fft <= p.n_samples;      // wave-uniform
-    const float pre = p.preemph;
+    inside = s_first >= 1 && s_last + p.n_fft <= p.n_samples;      // wave-uniform
+  };
+  auto prefetch = [&](int f0) {            // -> have_pf
+    have_pf = false;
+    if (!PF || f0 >= p.frames_per_group || t0 + f0 >= p.n_frames || pre != 0.0f) return;
+    int64_t tb, s_first; int nf; bool inside;
+    batch_geo(f0, tb, nf, s_first, inside);
+    if (!inside) return;
+#pragma unroll
+    for (int r = 0; r < (PF ? NR1 : 0); ++r) {
+      int tt = tid + 64 * r;
+      tt = tt < nf * R2 ? tt : nf * R2 - 1;               // clamped: no branch around a load
+      const int fr = tt / R2, j = tt - fr * R2;
+      const float* af = a + s_first + (int64_t)fr * p.hop + 2 * j;
+#pragma unroll
+      for (int t = 0; t < R1; ++t) {
+        const MmAnyFloat2U xv = *reinterpret_cast<const MmAnyFloat2U*>(af + 2 * R2 * t);
+        pf[r][t] = make_float2(xv.x, xv.y);
+      }
+    }
+    have_pf = true;
+  };
+  prefetch(0);
+  for (int f0 = 0; f0 < p.frames_per_group; f0 += FB) {
+    int64_t tb, s_first; int nf; bool inside;
+    if (t0 + f0 >= p.n_frames) break;                     // wave-uniform
+    batch_geo(f0, tb, nf, s_first, inside);
     // ---- stage 1: radix R1 from global memory (one task loop per way of loading: the choice is wave-uniform) ----
     auto stage1 = [&](auto load_pair) {
       for (int tt = tid; tt < nf * R2; tt += 64) {
@@ -87,7 +135,26 @@ __global__ __launch_bounds__(256) void stft_reg2_kernel(AnyParams p) {
         for (int u = 0; u < R1; ++u) o[u] = v[hb_perm<R1>(u)];
       }
     };
-    if (inside && pre == 0.0f) {
+    if (PF && have_pf) {
+      // the pairs are in registers (requested during the previous batch)
+#pragma unroll
+      for (int r = 0; r < (PF ? NR1 : 0); ++r) {
+        const int tt = tid + 64 * r;
+        if (tt < nf * R2) {
+          const int fr = tt / R2, j = tt - fr * R2;
+          hb_c<float> v[R1];
+#pragma unroll
+          for (int t = 0; t < R1; ++t) {
+            const float2 w = c_win2[j + R2 * t];
+            v[t].x = pf[r][t].x * w.x; v[t].y = pf[r][t].y * w.y;
+          }
+          hb_dft<float, R1>(v);
+          hb_c<float>* o = zA + fr * FP + j * BP;
+#pragma unroll
+          for (int u = 0; u < R1; ++u) o[u] = v[hb_perm<R1>(u)];
+        }
+      }
+    } else if (inside && pre == 0.0f) {
       stage1([&](int64_t s) {
         const MmAnyFloat2U xv = *reinterpret_cast<const MmAnyFloat2U*>(a + s);
         return make_float2(xv.x, xv.y);
@@ -106,14 +173,23 @@ __global__ __launch_bounds__(256) void stft_reg2_kernel(AnyParams p) {
       });
     }
     wave_lds_sync();
-    // ---- stage 2: radix 25, in place ----
+    prefetch(f0 + FB);
+    // ---- stage 2: radix R2, in place ----
     if (fr2 < nf) {
       hb_c<float>* zf = zA + fr2 * FP + k2;
       hb_c<float> v[R2];
 #pragma unroll
       for (int t = 0; t < R2; ++t) v[t] = zf[t * BP];
 #pragma unroll
-      for (int t = 1; t < R2; ++t) v[t] = hb_mul(v[t], tw2[t - 1]);
+      for (int t = 1; t < R2; ++t) {
+        if constexpr (PF) {
+          const float2 w = c_tw[k2 * t];
+          hb_c<float> ww; ww.x = w.x; ww.y = w.y;
+          v[t] = hb_mul(v[t], ww);
+        } else {
+          v[t] = hb_mul(v[t], tw2[t - 1]);
+        }
+      }
       hb_dft<float, R2>(v);
 #pragma unroll
       for (int u = 0; u < R2; ++u) zf[u * BP] = v[u];
