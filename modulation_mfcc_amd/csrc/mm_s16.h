@@ -1,4 +1,4 @@
-// The staged-sample n_fft = 512 kernel (mm_logmel16s.hip.inc) is its own translation unit (48 instantiations): this
+// The staged-sample n_fft = 512 kernel (mm_logmel16s.hip.inc) is its own translation unit (72 instantiations): this
 // header carries what the plan / dispatch code in mm_api.hip needs from it -- the LDS layout and the launch wrappers.
 #pragma once
 #include "mm_common.h"
