@@ -626,7 +626,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       // Filters without a single weight (fmax above Nyquist: 26 of the reference default's 128) are handled analytically
       // (Logmel512Params::skip_empty): their runs are flagged, their A-operand columns zero, E[k] follows the A operands.
       if (p->s16_nr && cfg->n_mels <= 256) {
-        const int lt_rows = (cfg->n_mels + 3) & ~3, nk = lt_rows / 4, kbn = (cfg->n_mfcc + 15) / 16;
+        const int lt_rows = (cfg->n_mels + 3) & ~3, kbn = (cfg->n_mfcc + 15) / 16;
         std::vector<char> empty(cfg->n_mels, 1);
         int n_empty = 0;
         for (int m = 0; m < cfg->n_mels; ++m) {
@@ -634,6 +634,15 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
           n_empty += empty[m];
         }
         const bool skip = n_empty > 0 && n_empty < cfg->n_mels;
+        // DCT steps (four filters each): the steps behind the last filter with a weight hold zero columns only -- the
+        // reference default's 26 empty filters are its top six steps of 32 -- and are not run (the f32 matrix instruction
+        // holds its SIMD's vector issue: every step is 32 cycles of the tile's time; measured 0.92 -> 0.90 ms)
+        int nk = lt_rows / 4;
+        if (skip) {
+          int last = cfg->n_mels - 1;
+          while (last > 0 && empty[last]) --last;
+          nk = last / 4 + 1;
+        }
         for (int layout = 0; layout < 2 && !p->s16f_ok; ++layout) {
           const bool single = layout == 1;
           const double wts_d[16] = {1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W, 1, 1, 1, MM_S16F_W};
