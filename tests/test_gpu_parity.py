@@ -1804,6 +1804,37 @@ def test_calls_are_graph_capturable(gpu):
     assert torch.equal(ms, plan.modspec(want))
 
 
+def test_plans_on_every_visible_device(gpu):
+    """One process, several GPUs (a host that drives more than one card from one interpreter): the raised dynamic-LDS limit
+    of a kernel is a PER-DEVICE function attribute (hipFuncSetAttribute acts on the current device), so the library keeps
+    its "already set" flags per device.  A plan on every visible device -- headline configuration (160 KB of LDS), the
+    reference default, a typed n_fft -- must launch and agree bit for bit with device 0.  Skipped on a one-GPU box."""
+    import torch
+    from modulation_mfcc_amd import MfccConfig, MfccPlan, calc
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("needs at least two visible GPUs")
+    cfgs = [dict(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0),
+            dict(sr=10000, n_fft=512, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0),
+            dict(sr=16000, n_fft=400, win_length=400, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0)]
+    host = np.stack([O.synth_clip(70 + i, 32000, 16000, ("am", "quiet_tail", "noise")[i % 3]) for i in range(256)])
+    for kw in cfgs:
+        want = None
+        for d in range(n_dev):
+            dev = torch.device("cuda", d)
+            plan = MfccPlan(MfccConfig(**kw), device=dev)
+            x = torch.from_numpy(host).to(dev)
+            m, s = plan.mfcc_modspec(x)
+            env = calc.hilbert_envelope_batch(x[:4])
+            got = (m.cpu(), s.cpu(), env.cpu())
+            if want is None:
+                want = got
+            else:
+                for a, b in zip(got, want):
+                    assert torch.equal(torch.view_as_real(a) if a.is_complex() else a,
+                                       torch.view_as_real(b) if b.is_complex() else b), (kw, d)
+
+
 def test_sharded_driver_single_rank_nccl(gpu):
     """The N > 1 code path (process group on RCCL, slab layout, gather, root-side modulation spectrum,
     the double-buffered PipelinedGather with its post hook) with a single-rank group: everything but
