@@ -15,6 +15,8 @@ cfg = MfccConfig(**kw)
 n = int(secs * cfg.sr)
 dev = torch.device("cuda", 0)
 plan = MfccPlan(cfg)
+if os.environ.get("MM_FUSE_TAIL"):
+    plan.set_fuse_tail(int(os.environ["MM_FUSE_TAIL"]))      # 0 separate launches, 1 default, 2 the wider one-launch forms
 audio = bench.synth_batch(torch, dev, B * ch, n, cfg.sr, 0)
 T = cfg.num_frames(n)
 out = torch.empty((B * ch, cfg.n_mfcc, T), device=dev)
