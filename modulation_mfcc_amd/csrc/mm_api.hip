@@ -530,6 +530,14 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       ce = &cfg_e; melp = mel_e.data(); winp = win_e.data(); p->embed = E;
     }
   }
+  // a window that is zero outside samples [128, 384) of its 512-point frame (win_length <= 256, centred: the reference's
+  // default 250; every n_fft <= 256 plan): the staged kernel reads and transforms a lane's middle eight pairs only
+  p->s16_halfwin = 0;
+  if (ce->n_fft == 512) {
+    bool z = true;
+    for (int i = 0; i < 128 && z; ++i) z = winp[i] == 0.0f && winp[511 - i] == 0.0f;
+    p->s16_halfwin = z ? 1 : 0;
+  }
   // register radix-16 path: n_fft 512; the 8-wave and the direct-load kernel need an even hop (8-byte
   // frame loads) and have no pre-emphasis: with an odd hop or pre-emphasis only the staged-sample
   // kernel applies (launch_stft sends the calls it cannot take to the generic kernel)
@@ -1164,7 +1172,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     q.out_mfcc = nullptr; q.key_nmin = nullptr; q.dct_a = nullptr; q.n_mfcc = 0; q.dct_nk = q.dct_kb = q.lt_rows = 0;
     q.lt_off = q.dcta_off = 0; q.dct_roles = ~0ull;
     q.out_mod = nullptr; q.dct_t = nullptr; q.n_mod = q.dct_kp = 0; q.top_db = -1.0f; q.red_off = 0;
-    q.dct_flags = 0; q.lt_b2 = 0;
+    q.dct_flags = p->s16_halfwin ? MM_S16F_HALFWIN : 0; q.lt_b2 = 0;
     q.lane_tab = p->d_lane_tab;
     q.preemph = p->cfg.preemph;
     if (q.n_tiles > 0x7FFFFFFF) return MM_ERR_INVALID_ARG;
@@ -1186,7 +1194,8 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
           q.out_mfcc = o.mfcc; q.key_nmin = o.key_nmin; q.dct_a = p->d_s16f_dcta; q.n_mfcc = p->cfg.n_mfcc;
           q.dct_nk = p->s16f_nk; q.dct_kb = p->s16f_kb; q.lt_rows = p->s16f_lt_rows;
           q.lt_off = p->s16f_lt_off; q.dcta_off = p->s16f_dcta_off; q.dct_roles = p->s16f_roles;
-          q.dct_flags = p->s16f_flags; q.lt_b2 = (p->s16f_flags & MM_S16F_SINGLE) ? 0 : p->s16f_lt_rows;
+          q.dct_flags = p->s16f_flags | (p->s16_halfwin ? MM_S16F_HALFWIN : 0);
+          q.lt_b2 = (p->s16f_flags & MM_S16F_SINGLE) ? 0 : p->s16f_lt_rows;
           if (p->cfg.top_db < 0.0f) q.out_logmel = nullptr;      // the rows only feed the clamp fix-up
           lds = p->s16f_lds_bytes;
           q.red_off = p->s16f_red_off;

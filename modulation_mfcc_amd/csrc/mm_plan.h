@@ -55,6 +55,7 @@ struct mm_plan {
   unsigned s16f_lt_off, s16f_dcta_off;
   unsigned long long s16f_roles;
   size_t s16f_lds_bytes;
+  int s16_halfwin;                 // the 512-point window is zero outside [128, 384): the staged kernel prunes its first stage
   int s16f_flags;                  // Logmel512Params::dct_flags (MM_S16F_SINGLE | MM_S16F_SKIP)
   // 12-wave MFMA-mel variant (mm_logmel12m.hip.inc)
   float *d_m12_a, *d_m12_dct, *d_zeros;
