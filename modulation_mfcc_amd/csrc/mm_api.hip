@@ -826,6 +826,34 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       bool attr_ok = p->wpf_lds_bytes <= MM_LM_LDS_MAX;
       for (int i = 0; i < 12 && attr_ok; ++i)
         attr_ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
+      // the highest bin any filter weighs: below NC / 2 the kernel forms no mirror bins and only the pairs up to it
+      {
+        int k_hi = 0;
+        for (int m = 0; m < cfg->n_mels; ++m)
+          for (int k = p->n_bins - 1; k > k_hi; --k)
+            if (mel[(size_t)m * p->n_bins + k] != 0.0f) { k_hi = k; break; }
+        p->wpf_half = (R >= 2 && k_hi < NC / 2) ? 1 : 0;
+        p->wpf_pairs = p->wpf_half ? std::max(4, k_hi / L + 1) : 8;
+        if (R == 4 && p->wpf_half && p->wpf_pairs <= 7) {
+          const void* nfn[8] = {(const void*)logmel_wpf_kernel<4, 1, false, false, 0, 4>, (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 5>,
+                                (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 6>, (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 7>,
+                                (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 4>, (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 5>,
+                                (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 6>, (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 7>};
+          for (int i = 0; i < 8; ++i)
+            if (hipFuncSetAttribute(nfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) p->wpf_half = 0;
+        }
+      }
+      // a window that leaves the first and last 3 / 16 of the frame zero (win_length <= 0.625 n_fft, centred -- BASELINE
+      // configs[3]: 1200 in 2048): the Z = 3 instantiations skip those pairs' loads, products and first-pass additions
+      p->wpf_z = 0;
+      if (R >= 2) {
+        const int lo = 6 * L, hi = 26 * L;            // samples [2 * 3 L, 2 * 13 L) may be non-zero
+        bool z = true;
+        for (int i = 0; i < cfg->n_fft && z; ++i) z = (i >= lo && i < hi) || win[i] == 0.0f;
+        if (z && hipFuncSetAttribute((const void*)logmel_wpf_kernel<2, 1, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess &&
+            hipFuncSetAttribute((const void*)logmel_wpf_kernel<4, 1, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess)
+          p->wpf_z = 3;
+      }
       if (ok && attr_ok && upload(&p->d_k2_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
           upload(&p->d_k2_mel_lane, ml.data(), ml.size() * 4) == MM_OK &&
           set_dct_fm_attr(64 * (MM_WPF_MAXMEL + 1) * 4))
@@ -1123,6 +1151,15 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     if (w16) {
       if (R == 2) hipLaunchKernelGGL((logmel_wpf_kernel<2, 1, false, true>), dim3((unsigned)grid), blk, lds, st, q);
       else hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, true>), dim3((unsigned)grid), blk, lds, st, q);
+    } else if (mode == 1 && !pre && R == 4 && p->wpf_half && p->wpf_pairs >= 4 && p->wpf_pairs <= 7) {
+      // n_fft 2048, a mel bank that ends below sr / 4: the output-pruned instantiations (with or without the input pruning)
+#define MM_WPF_NI(ZZ, NN) hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, false, ZZ, NN>), dim3((unsigned)grid), blk, lds, st, q)
+      if (p->wpf_z == 3) { switch (p->wpf_pairs) { case 4: MM_WPF_NI(3, 4); break; case 5: MM_WPF_NI(3, 5); break; case 6: MM_WPF_NI(3, 6); break; default: MM_WPF_NI(3, 7); } }
+      else { switch (p->wpf_pairs) { case 4: MM_WPF_NI(0, 4); break; case 5: MM_WPF_NI(0, 5); break; case 6: MM_WPF_NI(0, 6); break; default: MM_WPF_NI(0, 7); } }
+#undef MM_WPF_NI
+    } else if (p->wpf_z == 3 && mode == 1 && !pre && R >= 2) {
+      if (R == 2) hipLaunchKernelGGL((logmel_wpf_kernel<2, 1, false, false, 3>), dim3((unsigned)grid), blk, lds, st, q);
+      else hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, false, 3>), dim3((unsigned)grid), blk, lds, st, q);
     } else
     if (R == 1) { if (mode == 0) MM_WPF_LAUNCH(1, 0); else MM_WPF_LAUNCH(1, 1); }
     else if (R == 2) { if (mode == 0) MM_WPF_LAUNCH(2, 0); else MM_WPF_LAUNCH(2, 1); }
