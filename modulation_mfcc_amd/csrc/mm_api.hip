@@ -751,17 +751,33 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
     const int R = cfg->n_fft / 512, L = 16 * R, NC = 256 * R;
     mm::MelSweep sw2;
     if (mm::build_mel_sweep(*cfg, mel.data(), 1, &sw2)) {
-      std::vector<float> ml((size_t)L * 36, 0.0f);
-      std::vector<int> d_end(L, -2);
+      // the highest bin any filter weighs: below NC / 2 the n_fft 2048 kernel forms no mirror bins, only the split pairs up to
+      // it (NI = 4 .. 7), and its lanes sweep slices of EIGHT bins (64 lanes x 8 = bins 0 .. 511) instead of sixteen
+      {
+        int k_hi = 0;
+        for (int m = 0; m < cfg->n_mels; ++m)
+          for (int k = p->n_bins - 1; k > k_hi; --k)
+            if (mel[(size_t)m * p->n_bins + k] != 0.0f) { k_hi = k; break; }
+        p->wpf_half = (R == 4 && k_hi < NC / 2 && cfg->preemph == 0.0f) ? 1 : 0;
+        p->wpf_pairs = p->wpf_half ? std::max(4, k_hi / L + 1) : 8;
+        if (p->wpf_pairs > 7) p->wpf_half = 0;
+      }
+      std::vector<float> ml;
+      int group_max = 0;
       bool ok = true;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+      const int SL = p->wpf_half ? 8 : 16;                 // bins per lane of the sweep
+      ml.assign((size_t)L * 36, 0.0f);
+      std::vector<int> d_end(L, -2);
+      ok = true;
       for (int l = 0; l < L && ok; ++l) {
         float* r = ml.data() + l * 36;
-        int dprev = sw2.d[16 * l];
+        int dprev = sw2.d[SL * l];
         const int dstart = dprev;
         unsigned bits = 0;
-        const int nslots = (l == L - 1) ? 17 : 16;
+        const int nslots = SL == 8 ? 8 : ((l == L - 1) ? 17 : 16);
         for (int i = 0; i < nslots; ++i) {
-          const int k = (i < 16) ? 16 * l + i : NC;
+          const int k = (i < SL) ? SL * l + i : NC;
           const int adv = sw2.d[k] - dprev;
           if (adv < 0 || adv > 1) { ok = false; break; }
           if (adv == 1) bits |= (1u << i);
@@ -786,7 +802,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         for (int i = 0; i < 17; ++i) if ((bits >> i) & 1u) from = i;
         for (int i = from; i < 17; ++i) if (r[i] != 0.0f || r[17 + i] != 0.0f) act[l] = 1;
       }
-      int group_max = 0;
+      group_max = 0;
       for (int l = 0; l < L && ok; ++l) {
         if (!act[l]) continue;
         int first = l;
@@ -801,6 +817,9 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         if (last) bits |= 1u << 23;
         std::memcpy(&ml[(size_t)l * 36 + 35], &bits, 4);
       }
+      if (ok || !p->wpf_half) break;
+      p->wpf_half = 0; p->wpf_pairs = 8;                   // eight-bin slices do not fit this bank: the sixteen-bin tables
+      }
       p->wpf_group_max = group_max;
       std::vector<float> lt = wpf_lane_table(R, win.data(), tw.data());
       const int macc_stride = (cfg->n_mels + 2 + 63) / 64 * 64;      // slots -1 .. n_mels: no bounds tests in the sweep
@@ -809,6 +828,15 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       const int pbuf = F * (NC + NC / 16 + 4);
       const size_t wave_bytes = (size_t)(xbuf + pbuf + F * 3 * macc_stride) * 4;
       p->wpf_r = R;
+      // the half-band instantiations (NI < 8) need ~120 registers and a short power row: sixteen waves where the LDS has the
+      // room -- THEIR launch geometry only: the power stage and every other instantiation keep the twelve-wave layout
+      p->wpf_waves_half = 0; p->wpf_lds_half = 0;
+      if (p->wpf_half) {
+        const size_t wb = (size_t)(xbuf + MM_WPF_PBUF_HALF + F * 3 * macc_stride) * 4;
+        int wv = 16;
+        while (wv > 4 && (size_t)L * MM_WPF_LT_PITCH * 4 + wv * wb > MM_LM_LDS_MAX) wv -= 4;
+        p->wpf_waves_half = wv; p->wpf_lds_half = (size_t)L * MM_WPF_LT_PITCH * 4 + wv * wb;
+      }
       p->wpf_waves = 12;
       while (p->wpf_waves > 4 && (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes > MM_LM_LDS_MAX) p->wpf_waves -= 4;
       p->wpf_lds_bytes = (size_t)L * MM_WPF_LT_PITCH * 4 + p->wpf_waves * wave_bytes;
@@ -826,21 +854,14 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       bool attr_ok = p->wpf_lds_bytes <= MM_LM_LDS_MAX;
       for (int i = 0; i < 12 && attr_ok; ++i)
         attr_ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
-      // the highest bin any filter weighs: below NC / 2 the kernel forms no mirror bins and only the pairs up to it
       {
-        int k_hi = 0;
-        for (int m = 0; m < cfg->n_mels; ++m)
-          for (int k = p->n_bins - 1; k > k_hi; --k)
-            if (mel[(size_t)m * p->n_bins + k] != 0.0f) { k_hi = k; break; }
-        p->wpf_half = (R >= 2 && k_hi < NC / 2) ? 1 : 0;
-        p->wpf_pairs = p->wpf_half ? std::max(4, k_hi / L + 1) : 8;
         if (R == 4 && p->wpf_half && p->wpf_pairs <= 7) {
           const void* nfn[8] = {(const void*)logmel_wpf_kernel<4, 1, false, false, 0, 4>, (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 5>,
                                 (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 6>, (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 7>,
                                 (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 4>, (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 5>,
                                 (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 6>, (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 7>};
           for (int i = 0; i < 8; ++i)
-            if (hipFuncSetAttribute(nfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) p->wpf_half = 0;
+            if (hipFuncSetAttribute(nfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) attr_ok = false;   // (the tables are the eight-bin ones)
         }
       }
       // a window that leaves the first and last 3 / 16 of the frame zero (win_length <= 0.625 n_fft, centred -- BASELINE
@@ -1134,7 +1155,8 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
 #else
     const bool w16 = false;
 #endif
-    q.macc_stride = (p->cfg.n_mels + 2 + 63) / 64 * 64; q.waves_per_wg = w16 ? 16 : p->wpf_waves;
+    const bool half = mode == 1 && p->cfg.preemph == 0.0f && R == 4 && p->wpf_half && p->wpf_pairs >= 4 && p->wpf_pairs <= 7 && !w16;
+    q.macc_stride = (p->cfg.n_mels + 2 + 63) / 64 * 64; q.waves_per_wg = w16 ? 16 : (half ? p->wpf_waves_half : p->wpf_waves);
     q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane; q.group_max = p->wpf_group_max;
     q.out_logmel = o.logmel; q.clip_key = o.key_max; q.out_power = o.power;
     if (o.frame_major) { q.sB = q.n_frames * q.n_mels; q.sT = q.n_mels; q.sM = 1; }
@@ -1143,7 +1165,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     int64_t grid = (q.total_groups + q.waves_per_wg - 1) / q.waves_per_wg;
     if (grid > p->num_cus) grid = p->num_cus;
     const dim3 blk(64 * q.waves_per_wg);
-    const size_t lds = w16 ? p->wpf_lds16 : p->wpf_lds_bytes;
+    const size_t lds = w16 ? p->wpf_lds16 : (half ? p->wpf_lds_half : p->wpf_lds_bytes);
     q.preemph = p->cfg.preemph;
     const bool pre = p->cfg.preemph != 0.0f;
 #define MM_WPF_LAUNCH(RR, MM) do { if (pre) hipLaunchKernelGGL((logmel_wpf_kernel<RR, MM, true>), dim3((unsigned)grid), blk, lds, st, q); \
@@ -1151,7 +1173,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
     if (w16) {
       if (R == 2) hipLaunchKernelGGL((logmel_wpf_kernel<2, 1, false, true>), dim3((unsigned)grid), blk, lds, st, q);
       else hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, true>), dim3((unsigned)grid), blk, lds, st, q);
-    } else if (mode == 1 && !pre && R == 4 && p->wpf_half && p->wpf_pairs >= 4 && p->wpf_pairs <= 7) {
+    } else if (half) {
       // n_fft 2048, a mel bank that ends below sr / 4: the output-pruned instantiations (with or without the input pruning)
 #define MM_WPF_NI(ZZ, NN) hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, false, ZZ, NN>), dim3((unsigned)grid), blk, lds, st, q)
       if (p->wpf_z == 3) { switch (p->wpf_pairs) { case 4: MM_WPF_NI(3, 4); break; case 5: MM_WPF_NI(3, 5); break; case 6: MM_WPF_NI(3, 6); break; default: MM_WPF_NI(3, 7); } }

@@ -55,6 +55,7 @@ struct mm_plan {
   unsigned s16f_lt_off, s16f_dcta_off;
   unsigned long long s16f_roles;
   size_t s16f_lds_bytes;
+  int wpf_waves_half; size_t wpf_lds_half;   // launch geometry of the half-band instantiations (up to sixteen waves)
   int wpf_half, wpf_pairs;         // the mel bank reads no bin >= NC / 2: split pairs the kernel forms (WpfParams::n_pairs / half_band)
   int wpf_z;                       // 3: the window is zero for a lane's first and last three pairs (logmel_wpf_kernel<.., Z = 3>)
   int s16_halfwin;                 // the 512-point window is zero outside [128, 384): the staged kernel prunes its first stage
