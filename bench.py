@@ -76,6 +76,17 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def s16_kernel_key(cfg, mode):
+    """Name prefix of the staged-sample kernel instantiation a configuration runs on: logmel512s_kernel<MODE, NR, ...> with NR
+    the staging groups of its hop (1 / 2 / 3 / 4 for hop <= 56 / 121 / 186 / 252; pre-emphasis: at least 3) --
+    configs[1] (NR 3) and the reference default (NR 1) are different kernels with different traffic."""
+    hop = cfg.hop_length
+    nr = 1 if hop <= 56 else 2 if hop <= 121 else 3 if hop <= 186 else 4
+    if getattr(cfg, "preemph", 0.0):
+        nr = max(nr, 3)
+    return f"logmel512s_kernel<{mode}, {nr},"
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary that lists it
     (profiles/*_pmc.csv, written by tools/summarize_prof.py from separate FETCH_SIZE / WRITE_SIZE passes of
@@ -698,7 +709,7 @@ def main():
                 k = max(30, a.steps)
                 dt2, st2 = time_steps(torch, p2, lambda: p2.mfcc(rows2, out=out2), k, 10, ["logmel"])
                 ps = {kk: {"avg_ms": v[0] / v[1], "launches": v[1]} for kk, v in st2.items()}
-                key2 = {"radix16-w16s": "logmel512s_kernel<1", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(p2.kernel_path)
+                key2 = {"radix16-w16s": s16_kernel_key(c2, 1), "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(p2.kernel_path)
                 ex[name] = {"workload": workload_label(name, WORKLOADS[name][1], T2, c2, 0),
                              "metric": "MFCC frames/sec", "value": R2 * T2 * k / dt2, "unit": "frames/s",
                              "ms_per_step": 1e3 * dt2 / k, "steps": k, "kernel_path": p2.kernel_path,
@@ -721,7 +732,7 @@ def main():
                         "launches_per_step": 1 if ft3 else len(ps3),
                         "kernels_ms": {kk: round(v["avg_ms"], 4) for kk, v in ps3.items()},
                         "roofline": roofline_of(c2, R2, T2, nm2, True, ps3, p2.fused_dct,
-                                                "logmel512s_kernel<2" if ft3 else key2, fused_tail=ft3)}
+                                                s16_kernel_key(c2, 2) if ft3 else key2, fused_tail=ft3)}
                     if vec2 is not None:
                         ex[name]["with_modspec"]["check"] = compare_rows(np, out2, mod2, crow2, vec2)
                     del mod2
@@ -786,10 +797,10 @@ def main():
         fused = plan.fused_dct
         per_stage = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in stage.items()}
         res["kernels_ms"] = {k: round(v["avg_ms"], 4) for k, v in per_stage.items()}
-        key = {"radix16-w16s": "logmel512s_kernel<1", "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(plan.kernel_path)
+        key = {"radix16-w16s": s16_kernel_key(cfg, 1), "radix16-m12": "logmel12m", "radix16-wpf": "logmel_wpf"}.get(plan.kernel_path)
         ftail = bool(with_mod and not mod_on_root and plan.fused_tail(R, n))
         if ftail:
-            key = "logmel512s_kernel<2"         # the clip-mode instantiation
+            key = s16_kernel_key(cfg, 2)        # the clip-mode instantiation
         res["config"]["launches_per_step"] = 1 if ftail else (len(per_stage) if per_stage else None)
         res["config"]["fused_tail"] = ftail
         rl = roofline_of(cfg, R, T, n_mod, with_mod, per_stage, fused, key, fused_tail=ftail)
