@@ -758,7 +758,7 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         for (int m = 0; m < cfg->n_mels; ++m)
           for (int k = p->n_bins - 1; k > k_hi; --k)
             if (mel[(size_t)m * p->n_bins + k] != 0.0f) { k_hi = k; break; }
-        p->wpf_half = (R == 4 && k_hi < NC / 2 && cfg->preemph == 0.0f) ? 1 : 0;
+        p->wpf_half = (R >= 2 && k_hi < NC / 2 && cfg->preemph == 0.0f) ? 1 : 0;
         p->wpf_pairs = p->wpf_half ? std::max(4, k_hi / L + 1) : 8;
         if (p->wpf_pairs > 7) p->wpf_half = 0;
       }
@@ -855,12 +855,14 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
       for (int i = 0; i < 12 && attr_ok; ++i)
         attr_ok = hipFuncSetAttribute(kfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
       {
-        if (R == 4 && p->wpf_half && p->wpf_pairs <= 7) {
-          const void* nfn[8] = {(const void*)logmel_wpf_kernel<4, 1, false, false, 0, 4>, (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 5>,
-                                (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 6>, (const void*)logmel_wpf_kernel<4, 1, false, false, 0, 7>,
-                                (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 4>, (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 5>,
-                                (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 6>, (const void*)logmel_wpf_kernel<4, 1, false, false, 3, 7>};
-          for (int i = 0; i < 8; ++i)
+        if (p->wpf_half && p->wpf_pairs <= 7) {
+#define MM_WPF_NFN(RR) (const void*)logmel_wpf_kernel<RR, 1, false, false, 0, 4>, (const void*)logmel_wpf_kernel<RR, 1, false, false, 0, 5>, \
+                       (const void*)logmel_wpf_kernel<RR, 1, false, false, 0, 6>, (const void*)logmel_wpf_kernel<RR, 1, false, false, 0, 7>, \
+                       (const void*)logmel_wpf_kernel<RR, 1, false, false, 3, 4>, (const void*)logmel_wpf_kernel<RR, 1, false, false, 3, 5>, \
+                       (const void*)logmel_wpf_kernel<RR, 1, false, false, 3, 6>, (const void*)logmel_wpf_kernel<RR, 1, false, false, 3, 7>
+          const void* nfn[16] = {MM_WPF_NFN(4), MM_WPF_NFN(2)};
+#undef MM_WPF_NFN
+          for (int i = 0; i < 16; ++i)
             if (hipFuncSetAttribute(nfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) attr_ok = false;   // (the tables are the eight-bin ones)
         }
       }
@@ -1155,7 +1157,7 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
 #else
     const bool w16 = false;
 #endif
-    const bool half = mode == 1 && p->cfg.preemph == 0.0f && R == 4 && p->wpf_half && p->wpf_pairs >= 4 && p->wpf_pairs <= 7 && !w16;
+    const bool half = mode == 1 && p->cfg.preemph == 0.0f && R >= 2 && p->wpf_half && p->wpf_pairs >= 4 && p->wpf_pairs <= 7 && !w16;
     q.macc_stride = (p->cfg.n_mels + 2 + 63) / 64 * 64; q.waves_per_wg = w16 ? 16 : (half ? p->wpf_waves_half : p->wpf_waves);
     q.lane_tab = p->d_k2_lane_tab; q.mel_lane = p->d_k2_mel_lane; q.group_max = p->wpf_group_max;
     q.out_logmel = o.logmel; q.clip_key = o.key_max; q.out_power = o.power;
@@ -1174,10 +1176,13 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
       if (R == 2) hipLaunchKernelGGL((logmel_wpf_kernel<2, 1, false, true>), dim3((unsigned)grid), blk, lds, st, q);
       else hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, true>), dim3((unsigned)grid), blk, lds, st, q);
     } else if (half) {
-      // n_fft 2048, a mel bank that ends below sr / 4: the output-pruned instantiations (with or without the input pruning)
-#define MM_WPF_NI(ZZ, NN) hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, false, ZZ, NN>), dim3((unsigned)grid), blk, lds, st, q)
-      if (p->wpf_z == 3) { switch (p->wpf_pairs) { case 4: MM_WPF_NI(3, 4); break; case 5: MM_WPF_NI(3, 5); break; case 6: MM_WPF_NI(3, 6); break; default: MM_WPF_NI(3, 7); } }
-      else { switch (p->wpf_pairs) { case 4: MM_WPF_NI(0, 4); break; case 5: MM_WPF_NI(0, 5); break; case 6: MM_WPF_NI(0, 6); break; default: MM_WPF_NI(0, 7); } }
+      // n_fft 1024 / 2048, a mel bank that ends below sr / 4: the output-pruned instantiations (with or without the input pruning)
+#define MM_WPF_NI(RR, ZZ, NN) hipLaunchKernelGGL((logmel_wpf_kernel<RR, 1, false, false, ZZ, NN>), dim3((unsigned)grid), blk, lds, st, q)
+#define MM_WPF_NIS(RR, ZZ) switch (p->wpf_pairs) { case 4: MM_WPF_NI(RR, ZZ, 4); break; case 5: MM_WPF_NI(RR, ZZ, 5); break; \
+                                                   case 6: MM_WPF_NI(RR, ZZ, 6); break; default: MM_WPF_NI(RR, ZZ, 7); }
+      if (R == 4) { if (p->wpf_z == 3) { MM_WPF_NIS(4, 3) } else { MM_WPF_NIS(4, 0) } }
+      else { if (p->wpf_z == 3) { MM_WPF_NIS(2, 3) } else { MM_WPF_NIS(2, 0) } }
+#undef MM_WPF_NIS
 #undef MM_WPF_NI
     } else if (p->wpf_z == 3 && mode == 1 && !pre && R >= 2) {
       if (R == 2) hipLaunchKernelGGL((logmel_wpf_kernel<2, 1, false, false, 3>), dim3((unsigned)grid), blk, lds, st, q);

@@ -818,6 +818,48 @@ def test_clip_mode_with_a_2048_point_trajectory(n, B, gpu):
     assert torch.allclose(e_time, e_freq, rtol=1e-4)
 
 
+_HALFBAND_CFGS = [
+    # (cfg, what): n_fft 1024 / 2048 plans whose mel bank ends below sr / 4 -- the output-pruned wave-per-frame instantiations
+    (dict(sr=48000, n_fft=2048, win_length=1200, hop_length=480, n_mels=80, n_mfcc=40, fmin=100.0, fmax=10000.0), "BASELINE configs[3]: Z 3, 7 pairs"),
+    (dict(sr=44100, n_fft=2048, win_length=2048, hop_length=512, n_mels=64, n_mfcc=20, fmin=0.0, fmax=8000.0), "full window, 6 pairs"),
+    (dict(sr=48000, n_fft=2048, win_length=1024, hop_length=256, n_mels=40, n_mfcc=13, fmin=50.0, fmax=3000.0), "Z 3, 4 pairs (bank ends at bin 128)"),
+    (dict(sr=44100, n_fft=2048, win_length=1280, hop_length=441, n_mels=96, n_mfcc=13, fmin=100.0, fmax=9000.0), "96 mel; the window's edge case for Z 3"),
+    (dict(sr=44100, n_fft=1024, win_length=1024, hop_length=256, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "n_fft 1024, 6 pairs"),
+    (dict(sr=48000, n_fft=1024, win_length=600, hop_length=240, n_mels=32, n_mfcc=20, fmin=100.0, fmax=5000.0), "n_fft 1024, Z 3, 4 pairs"),
+    (dict(sr=22050, n_fft=1024, win_length=640, hop_length=221, n_mels=48, n_mfcc=13, fmin=0.0, fmax=5400.0, top_db=40.0), "n_fft 1024, odd hop, 8 pairs' edge (k_hi 251)"),
+]
+
+
+@pytest.mark.parametrize("kw,what", _HALFBAND_CFGS, ids=[f"halfband{i}" for i in range(len(_HALFBAND_CFGS))])
+def test_half_band_wave_per_frame_kernels(kw, what, gpu):
+    """A window that leaves a lane's first / last stage-1 pairs zero and a mel bank that ends below sr / 4 select the pruned
+    instantiations of logmel_wpf_kernel (Z = 3; NI = 4 .. 7 with eight-bin sweep slices, up to sixteen waves per CU, stage 3
+    through DPP): MFCC, log-mel rows and the power stage (which always runs the full kernel) against the oracle on clips of
+    every kind and ragged lengths, and MFCC + modulation spectrum in one call."""
+    plan = _plan(kw)
+    assert plan.kernel_path == "radix16-wpf"
+    ocfg = O.OracleConfig(**dict(kw, top_db=kw.get("top_db", 80.0)))
+    hop, n_fft = kw["hop_length"], kw["n_fft"]
+    for n in (n_fft // 2 + 3, 7 * hop + n_fft + 1, 40 * hop + 5 * n_fft):
+        clips = np.stack([O.synth_clip(500 + i, n, kw["sr"], k) for i, k in enumerate(("am", "quiet_tail", "noise", "impulse", "silence"))])
+        got = plan.mfcc(_dev(clips, gpu)).cpu().numpy()
+        for i in range(len(clips)):
+            want = O.mfcc(clips[i], ocfg)
+            assert got[i].shape == want.shape
+            mfcc_close(got[i], want, f"{what}: n {n} clip {i}")
+    y = clips[0]
+    lm, mx = plan.logmel(_dev(y, gpu)[None, :])
+    lw = O.logmel_unclamped(y, ocfg).T
+    assert np.abs(lm[0].cpu().numpy() - lw).max() <= 2e-2 and abs(float(mx[0]) - lw.max()) <= 1e-3
+    P = plan.stft_power(_dev(y, gpu)[None, :])[0].cpu().numpy()
+    Pw = O.stft_power(y, n_fft, hop, kw["win_length"], 0.0)
+    assert np.abs(P - Pw).max() <= 2e-5 * Pw.max()
+    m2, s2 = plan.mfcc_modspec(_dev(clips, gpu))
+    np.testing.assert_array_equal(m2.cpu().numpy(), got)
+    wm = O.modspec(got[0])
+    assert np.abs(s2[0].cpu().numpy() - wm).max() <= 1e-4 * max(np.abs(wm).max(), 1e-30)
+
+
 def test_modulation_spectrum_of_long_trajectories(gpu):
     """Row A8 beyond 8192 frames per clip -- what the reference's own default step makes of a recording (tStep = 0.001,
     script/mfcc.py:296: 10 001 frames per ten seconds; a one-minute file: 60 001): mm_modspec_f32 stops at 8192 points,
