@@ -866,16 +866,27 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
             if (hipFuncSetAttribute(nfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) != hipSuccess) attr_ok = false;   // (the tables are the eight-bin ones)
         }
       }
-      // a window that leaves the first and last 3 / 16 of the frame zero (win_length <= 0.625 n_fft, centred -- BASELINE
-      // configs[3]: 1200 in 2048): the Z = 3 instantiations skip those pairs' loads, products and first-pass additions
+      // a window that leaves the first and last Z / 16 of the frame zero (centred): the Z instantiations skip those pairs' loads,
+      // products and additions -- 3 (win_length <= 0.625 n_fft: BASELINE configs[3], 1200 in 2048), and 5 / 6 / 7 for the
+      // zero-padded frames the reference's dialog produces (n_fft typed, winLen 25 ms: 250 samples in 1024 -> 6, in 2048 -> 7)
       p->wpf_z = 0;
       if (R >= 2) {
-        const int lo = 6 * L, hi = 26 * L;            // samples [2 * 3 L, 2 * 13 L) may be non-zero
-        bool z = true;
-        for (int i = 0; i < cfg->n_fft && z; ++i) z = (i >= lo && i < hi) || win[i] == 0.0f;
-        if (z && hipFuncSetAttribute((const void*)logmel_wpf_kernel<2, 1, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess &&
-            hipFuncSetAttribute((const void*)logmel_wpf_kernel<4, 1, false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess)
-          p->wpf_z = 3;
+        int zmax = 0;
+        for (int zz = 1; zz <= 7; ++zz) {
+          bool z = true;
+          for (int i = 2 * L * (zz - 1); i < 2 * L * zz && z; ++i) z = win[i] == 0.0f && win[cfg->n_fft - 1 - i] == 0.0f;
+          if (!z) break;
+          zmax = zz;
+        }
+        const int zsel = zmax >= 7 ? 7 : zmax >= 6 ? 6 : zmax >= 5 ? 5 : zmax >= 3 ? 3 : 0;
+        const void* zfn[8] = {(const void*)logmel_wpf_kernel<2, 1, false, false, 3>, (const void*)logmel_wpf_kernel<4, 1, false, false, 3>,
+                              (const void*)logmel_wpf_kernel<2, 1, false, false, 5>, (const void*)logmel_wpf_kernel<4, 1, false, false, 5>,
+                              (const void*)logmel_wpf_kernel<2, 1, false, false, 6>, (const void*)logmel_wpf_kernel<4, 1, false, false, 6>,
+                              (const void*)logmel_wpf_kernel<2, 1, false, false, 7>, (const void*)logmel_wpf_kernel<4, 1, false, false, 7>};
+        bool zok = zsel > 0;
+        for (int i = 0; i < 8 && zok; ++i)
+          zok = hipFuncSetAttribute(zfn[i], hipFuncAttributeMaxDynamicSharedMemorySize, MM_LM_LDS_MAX) == hipSuccess;
+        if (zok) p->wpf_z = zsel;
       }
       if (ok && attr_ok && upload(&p->d_k2_lane_tab, lt.data(), lt.size() * 4) == MM_OK &&
           upload(&p->d_k2_mel_lane, ml.data(), ml.size() * 4) == MM_OK &&
@@ -1180,13 +1191,17 @@ static int launch_stft(mm_plan* p, int mode, const float* d_audio, int64_t batch
 #define MM_WPF_NI(RR, ZZ, NN) hipLaunchKernelGGL((logmel_wpf_kernel<RR, 1, false, false, ZZ, NN>), dim3((unsigned)grid), blk, lds, st, q)
 #define MM_WPF_NIS(RR, ZZ) switch (p->wpf_pairs) { case 4: MM_WPF_NI(RR, ZZ, 4); break; case 5: MM_WPF_NI(RR, ZZ, 5); break; \
                                                    case 6: MM_WPF_NI(RR, ZZ, 6); break; default: MM_WPF_NI(RR, ZZ, 7); }
-      if (R == 4) { if (p->wpf_z == 3) { MM_WPF_NIS(4, 3) } else { MM_WPF_NIS(4, 0) } }
-      else { if (p->wpf_z == 3) { MM_WPF_NIS(2, 3) } else { MM_WPF_NIS(2, 0) } }
+      if (R == 4) { if (p->wpf_z >= 3) { MM_WPF_NIS(4, 3) } else { MM_WPF_NIS(4, 0) } }
+      else { if (p->wpf_z >= 3) { MM_WPF_NIS(2, 3) } else { MM_WPF_NIS(2, 0) } }
 #undef MM_WPF_NIS
 #undef MM_WPF_NI
-    } else if (p->wpf_z == 3 && mode == 1 && !pre && R >= 2) {
-      if (R == 2) hipLaunchKernelGGL((logmel_wpf_kernel<2, 1, false, false, 3>), dim3((unsigned)grid), blk, lds, st, q);
-      else hipLaunchKernelGGL((logmel_wpf_kernel<4, 1, false, false, 3>), dim3((unsigned)grid), blk, lds, st, q);
+    } else if (p->wpf_z >= 3 && mode == 1 && !pre && R >= 2) {
+#define MM_WPF_Z(RR, ZZ) hipLaunchKernelGGL((logmel_wpf_kernel<RR, 1, false, false, ZZ>), dim3((unsigned)grid), blk, lds, st, q)
+#define MM_WPF_ZS(RR) switch (p->wpf_z) { case 7: MM_WPF_Z(RR, 7); break; case 6: MM_WPF_Z(RR, 6); break; case 5: MM_WPF_Z(RR, 5); break; \
+                                          default: MM_WPF_Z(RR, 3); }
+      if (R == 2) { MM_WPF_ZS(2) } else { MM_WPF_ZS(4) }
+#undef MM_WPF_ZS
+#undef MM_WPF_Z
     } else
     if (R == 1) { if (mode == 0) MM_WPF_LAUNCH(1, 0); else MM_WPF_LAUNCH(1, 1); }
     else if (R == 2) { if (mode == 0) MM_WPF_LAUNCH(2, 0); else MM_WPF_LAUNCH(2, 1); }

@@ -827,6 +827,12 @@ _HALFBAND_CFGS = [
     (dict(sr=44100, n_fft=1024, win_length=1024, hop_length=256, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "n_fft 1024, 6 pairs"),
     (dict(sr=48000, n_fft=1024, win_length=600, hop_length=240, n_mels=32, n_mfcc=20, fmin=100.0, fmax=5000.0), "n_fft 1024, Z 3, 4 pairs"),
     (dict(sr=22050, n_fft=1024, win_length=640, hop_length=221, n_mels=48, n_mfcc=13, fmin=0.0, fmax=5400.0, top_db=40.0), "n_fft 1024, odd hop, 8 pairs' edge (k_hi 251)"),
+    # zero-padded frames: the reference's dialog lets the user type n_fft while winLen stays 25 ms (script/main.py:1049-1066)
+    (dict(sr=10000, n_fft=1024, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "UI defaults, n_fft 1024 typed: Z 6"),
+    (dict(sr=10000, n_fft=2048, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "UI defaults, n_fft 2048 typed: Z 7"),
+    (dict(sr=16000, n_fft=2048, win_length=640, hop_length=160, n_mels=80, n_mfcc=13, fmin=100.0, fmax=8000.0), "Z 5, full band"),
+    (dict(sr=16000, n_fft=1024, win_length=321, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "n_fft 1024, odd window, Z 5"),
+    (dict(sr=48000, n_fft=2048, win_length=500, hop_length=240, n_mels=64, n_mfcc=20, fmin=100.0, fmax=10000.0), "Z 6 window with a half-band bank (the Z 3 half-band instantiation)"),
 ]
 
 
