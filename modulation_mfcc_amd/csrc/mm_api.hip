@@ -790,8 +790,8 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         d_end[l] = dprev;
       }
       // lanes whose sweep ends in the same run form a contiguous group: distance to its first lane in
-      // bits 20..22 of the flag word, "last lane of the group" in bit 23 (the kernel pre-sums a group
-      // in registers, at most 8 lanes)
+      // bits 20..23 of the flag word, "last lane of the group" in bit 24 (the kernel pre-sums a group
+      // in registers, at most 16 lanes)
       // (lanes whose remaining weights are all zero -- bins above fmax -- take no part)
       std::vector<char> act(L, 0);
       for (int l = 0; l < L; ++l) {
@@ -809,12 +809,13 @@ int mm_plan_create(const mm_config* cfg, mm_plan** out) {
         while (first > 0 && act[first - 1] && d_end[first - 1] == d_end[l]) --first;
         const int dist = l - first;
         const bool last = (l == L - 1) || !act[l + 1] || d_end[l + 1] != d_end[l];
-        if (dist > 7) { ok = false; break; }
+        if (dist > 15) { ok = false; break; }     // (four bits: the last filter's run -- rising and falling part, no successor -- of a
+                                                  //  40-filter bank at n_fft 2048 spans nine lanes)
         group_max = std::max(group_max, dist);
         unsigned bits;
         std::memcpy(&bits, &ml[(size_t)l * 36 + 35], 4);
         bits |= (unsigned)dist << 20;
-        if (last) bits |= 1u << 23;
+        if (last) bits |= 1u << 24;
         std::memcpy(&ml[(size_t)l * 36 + 35], &bits, 4);
       }
       if (ok || !p->wpf_half) break;

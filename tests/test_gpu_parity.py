@@ -831,6 +831,7 @@ _HALFBAND_CFGS = [
     (dict(sr=10000, n_fft=1024, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "UI defaults, n_fft 1024 typed: Z 6"),
     (dict(sr=10000, n_fft=2048, win_length=250, hop_length=50, n_mels=128, n_mfcc=13, fmin=100.0, fmax=10000.0), "UI defaults, n_fft 2048 typed: Z 7"),
     (dict(sr=16000, n_fft=2048, win_length=640, hop_length=160, n_mels=80, n_mfcc=13, fmin=100.0, fmax=8000.0), "Z 5, full band"),
+    (dict(sr=16000, n_fft=2048, win_length=2048, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "few wide filters: the last run spans nine lanes (used to fall to the generic kernel)"),
     (dict(sr=16000, n_fft=1024, win_length=321, hop_length=160, n_mels=40, n_mfcc=13, fmin=100.0, fmax=8000.0), "n_fft 1024, odd window, Z 5"),
     (dict(sr=48000, n_fft=2048, win_length=500, hop_length=240, n_mels=64, n_mfcc=20, fmin=100.0, fmax=10000.0), "Z 6 window with a half-band bank (the Z 3 half-band instantiation)"),
 ]
