@@ -351,3 +351,23 @@ def test_iir_design_cache_does_not_accept_what_scipy_rejects():
                 filters.iir_sos(200.0, cutOff=[12], filtLen=bad)
         else:                                  # scipy accepts it (True == order 1): the same sections, uncached
             np.testing.assert_array_equal(filters.iir_sos(200.0, cutOff=[12], filtLen=bad), want)
+
+
+def test_bench_names_the_kernel_instantiation_of_a_workload():
+    """bench.py reads a kernel's HBM traffic from the committed counter summaries by kernel NAME: the staged-sample kernel's
+    instantiations differ by their staging groups (NR follows the hop: DESIGN.md 4.0), so BASELINE configs[1] / [2] (hop 160: NR 3)
+    and the reference's default call (hop 50: NR 1) must not share a key -- they did, and configs[1] was reported with the
+    reference default's traffic."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from modulation_mfcc_amd import MfccConfig
+    c16 = MfccConfig(**bench.WORKLOADS["c3"][4])
+    rd = MfccConfig(**bench.WORKLOADS["refdefault"][4])
+    assert bench.s16_kernel_key(c16, 1) == "logmel512s_kernel<1, 3,"
+    assert bench.s16_kernel_key(c16, 2) == "logmel512s_kernel<2, 3,"
+    assert bench.s16_kernel_key(rd, 1) == "logmel512s_kernel<1, 1,"
+    for hop, nr in ((56, 1), (57, 2), (121, 2), (122, 3), (186, 3), (187, 4), (252, 4)):
+        assert bench.s16_kernel_key(MfccConfig(**dict(bench.WORKLOADS["c3"][4], hop_length=hop)), 1) == f"logmel512s_kernel<1, {nr},"
+    assert bench.s16_kernel_key(MfccConfig(**dict(bench.WORKLOADS["refdefault"][4], preemph=0.97)), 1) == "logmel512s_kernel<1, 3,"
